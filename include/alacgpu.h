@@ -1,0 +1,174 @@
+/*
+ * alacgpu.h — C ABI of the MI355X (gfx950) batch ALAC packet decoder.
+ *
+ * This is the drop-in boundary for the reference's packet layer
+ * (mycophonic/saprobe-alac, paths relative to the reference tree):
+ *
+ *   reference (Go)                                   this ABI
+ *   ------------------------------------------------ ---------------------------
+ *   PacketConfig            config.go:27-38          alacgpu_config
+ *   PCMFormat               format.go:20-24          alacgpu_format
+ *   NewPacketDecoder        decoder.go:90-109        alacgpu_create
+ *   (*PacketDecoder).Format decoder.go:112-114       alacgpu_get_format
+ *   (*PacketDecoder).DecodePacket  decoder.go:117-128  alacgpu_decode_packet
+ *   decodePacketInto        decoder.go:133-207       alacgpu_decode_packet (caller buffer)
+ *   DecodePackets (new batch entry, north star)      alacgpu_decode_batch / _device
+ *   ErrDecode + internal sentinels errors.go:22-34,  alacgpu_status (per packet)
+ *                           internal/alac/errors.go:24-33
+ *
+ * Plain pointers and sizes only; no C++ or torch types. All functions are
+ * re-entrant across different handles; one handle is single-caller, like a
+ * PacketDecoder (decoder.go:79-87 holds mutable scratch).
+ *
+ * There is NO CPU decode path behind this ABI: every decode entry runs the HIP
+ * kernels on the handle's device and returns ALACGPU_E_HIP if that fails.
+ */
+#ifndef ALACGPU_H
+#define ALACGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors PacketConfig (config.go:27-38) field for field. */
+typedef struct alacgpu_config {
+    uint32_t frame_length;    /* FrameLength   */
+    uint8_t  bit_depth;       /* BitDepth: 16, 20, 24 or 32 */
+    uint8_t  num_channels;    /* NumChannels: 1..8 */
+    uint8_t  pb;              /* PB */
+    uint8_t  mb;              /* MB */
+    uint8_t  kb;              /* KB */
+    uint8_t  reserved0;
+    uint16_t max_run;         /* MaxRun (stored, never read by decode) */
+    uint32_t max_frame_bytes; /* MaxFrameBytes */
+    uint32_t avg_bit_rate;    /* AvgBitRate */
+    uint32_t sample_rate;     /* SampleRate */
+} alacgpu_config;
+
+/* Mirrors PCMFormat (format.go:20-24). */
+typedef struct alacgpu_format {
+    int32_t sample_rate;
+    int32_t bit_depth;
+    int32_t channels;
+} alacgpu_format;
+
+/*
+ * Per-packet status word (int32).
+ *   bits 0..7   code      (alacgpu_code) — which internal sentinel
+ *   bits 8..11  context   (alacgpu_ctx)  — the wrapping string the reference adds
+ *   bits 12..13 stage     (alacgpu_stage)— "entropy decode" / "entropy decode U|V"
+ * 0 means success. The Go shim rebuilds the reference's error chain from it:
+ *   fmt.Errorf("%w: <ctx>: <stage>: %w", ErrDecode, <sentinel>)
+ */
+typedef enum alacgpu_code {
+    ALACGPU_OK                     = 0,
+    ALACGPU_ERR_BITSTREAM_OVERRUN  = 1, /* ErrBitstreamOverrun   internal/alac/errors.go:30 */
+    ALACGPU_ERR_SAMPLE_OVERRUN     = 2, /* ErrSampleOverrun      internal/alac/errors.go:31 */
+    ALACGPU_ERR_INVALID_HEADER     = 3, /* ErrInvalidHeader      internal/alac/errors.go:28 */
+    ALACGPU_ERR_INVALID_SHIFT      = 4, /* ErrInvalidShift       internal/alac/errors.go:29 */
+    ALACGPU_ERR_UNSUPPORTED_ELEMENT= 5, /* ErrUnsupportedElement internal/alac/errors.go:27 */
+    ALACGPU_ERR_MALFORMED          = 6  /* input on which the Go reference panics (slice bounds);
+                                           it has no defined result there, we return a status */
+} alacgpu_code;
+
+typedef enum alacgpu_ctx {
+    ALACGPU_CTX_NONE = 0,
+    ALACGPU_CTX_SCE  = 1, /* "SCE/LFE" decoder.go:156 */
+    ALACGPU_CTX_CPE  = 2, /* "CPE"     decoder.go:173 */
+    ALACGPU_CTX_DSE  = 3, /* "DSE"     decoder.go:184 */
+    ALACGPU_CTX_FIL  = 4  /* "FIL"     decoder.go:189 */
+} alacgpu_ctx;
+
+typedef enum alacgpu_stage {
+    ALACGPU_STAGE_NONE      = 0,
+    ALACGPU_STAGE_ENTROPY   = 1, /* "entropy decode"   decoder.go:303 */
+    ALACGPU_STAGE_ENTROPY_U = 2, /* "entropy decode U" decoder.go:468 */
+    ALACGPU_STAGE_ENTROPY_V = 3  /* "entropy decode V" decoder.go:482 */
+} alacgpu_stage;
+
+#define ALACGPU_STATUS(code, ctx, stage) ((int32_t)((code) | ((ctx) << 8) | ((stage) << 12)))
+#define ALACGPU_STATUS_CODE(s)  ((s) & 0xff)
+#define ALACGPU_STATUS_CTX(s)   (((s) >> 8) & 0xf)
+#define ALACGPU_STATUS_STAGE(s) (((s) >> 12) & 0x3)
+
+/* Call-level return values (negative = the call itself failed). */
+#define ALACGPU_E_OK        0
+#define ALACGPU_E_CONFIG   -1  /* ErrConfig: unsupported bit depth (decoder.go:91-93) or
+                                  NumChannels outside 1..8 (the reference index-panics at decoder.go:140) */
+#define ALACGPU_E_ARG      -2  /* null pointer / capacity too small */
+#define ALACGPU_E_HIP      -3  /* HIP runtime failure; see alacgpu_last_error */
+#define ALACGPU_E_DECODE   -4  /* alacgpu_decode_packet only: packet failed, *status_out holds the word */
+
+/* Every packet in a device-resident blob must be followed by at least this many
+ * zero bytes (the reference pads each packet with 4, bitbuffer.go:33; the kernel
+ * prefetches a little further). alacgpu_decode_batch re-packs host input itself. */
+#define ALACGPU_PACKET_PAD 16
+
+typedef struct alacgpu_decoder alacgpu_decoder;
+
+/* NewPacketDecoder (decoder.go:90). device = HIP ordinal; one stream per handle. */
+int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out);
+void alacgpu_destroy(alacgpu_decoder* dec);
+
+/* (*PacketDecoder).Format (decoder.go:112). */
+int alacgpu_get_format(const alacgpu_decoder* dec, alacgpu_format* fmt);
+
+/* Bytes of one full decoded frame: FrameLength*NumChannels*BytesPerSample (decoder.go:120). */
+size_t alacgpu_frame_bytes(const alacgpu_decoder* dec);
+
+/*
+ * DecodePacket / decodePacketInto (decoder.go:117,133): one packet, host buffers,
+ * through the same HIP kernel as the batch entry (batch of 1). out_cap must be
+ * >= alacgpu_frame_bytes(). *out_len = numSamples*numChan*bps (decoder.go:206).
+ * Returns ALACGPU_E_DECODE and sets *status_out when the packet fails.
+ */
+int alacgpu_decode_packet(alacgpu_decoder* dec, const uint8_t* packet, size_t packet_len,
+                          uint8_t* out, size_t out_cap, size_t* out_len, int32_t* status_out);
+
+/*
+ * DecodePackets, host buffers. Packet i is blob[offsets[i] .. offsets[i+1]).
+ * PCM of packet i is written at out + i*out_stride (out_stride >= frame bytes);
+ * frames_out[i] = the packet's sample-frame count (0 on failure), status[i] = status word.
+ * A failing packet leaves its output slot unspecified and does not affect others.
+ */
+int alacgpu_decode_batch(alacgpu_decoder* dec, const uint8_t* blob, const uint64_t* offsets,
+                         size_t n_packets, uint8_t* out, size_t out_stride,
+                         uint32_t* frames_out, int32_t* status);
+
+/*
+ * DecodePackets, device-resident (the benchmark path). All pointers are device
+ * pointers on the handle's device. Packet i is d_blob[d_offsets[i] .. +d_sizes[i])
+ * followed by >= ALACGPU_PACKET_PAD zero bytes. Asynchronous on the handle's
+ * stream unless sync != 0.
+ */
+int alacgpu_decode_batch_device(alacgpu_decoder* dec, const uint8_t* d_blob,
+                                const uint64_t* d_offsets, const uint32_t* d_sizes,
+                                size_t n_packets, uint8_t* d_out, size_t out_stride,
+                                uint32_t* d_frames_out, int32_t* d_status, int sync);
+
+/* Device scratch the handle needs for a batch of n packets (grown on demand by the
+ * batch entries; exposed so callers can pre-size before timing). */
+int alacgpu_reserve(alacgpu_decoder* dec, size_t n_packets);
+
+/* Time of the last decode kernel launch on this handle in milliseconds, measured with
+ * HIP events on the handle's stream (valid after a sync). Used by bench.py's roofline. */
+int alacgpu_last_kernel_ms(alacgpu_decoder* dec, float* ms);
+
+/* The handle's hipStream_t as an opaque pointer (for callers that enqueue copies). */
+void* alacgpu_stream(alacgpu_decoder* dec);
+
+int alacgpu_synchronize(alacgpu_decoder* dec);
+
+/* Thread-local description of the last ALACGPU_E_HIP / E_ARG / E_CONFIG failure. */
+const char* alacgpu_last_error(void);
+
+/* "alacgpu <semver> gfx950" */
+const char* alacgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALACGPU_H */
