@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s decoded (16-bit stereo, 4096-frame packets) on N MI355X.
+
+A "step" is one pass of the hot path (alacgpu_decode_batch_device: entropy decode -> predictor ->
+unmix -> interleaved LE PCM) over one batch of synthetic packets that is already resident in HBM.
+Weak scaling: every rank decodes its own --packets packets (default 65 536, the north-star batch);
+ranks share nothing (no collective on the data path), `value` = samples decoded by all ranks per
+second of the slowest rank. samples = frames x channels.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (HBM, algorithmic
+bytes / HIP-event kernel time) and, at N=1, `cpu_baseline` (the C oracle on the host cores).
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--packets", type=int, default=65536, help="packets per GPU (weak scaling)")
+    ap.add_argument("--depth", type=int, default=16)
+    ap.add_argument("--channels", type=int, default=2)
+    ap.add_argument("--frame-length", type=int, default=4096)
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gen-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 64))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        # started by hand without the launcher: start it as a child before anything touches the GPU
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    pkg = importlib.import_module("saprobe-alac_amd")
+    synth = importlib.import_module("saprobe-alac_amd.synth")
+    if not os.path.exists(pkg.lib_path()):
+        pkg.build()
+    synth.build()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU decode path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    P, FL, depth, ch = args.packets, args.frame_length, args.depth, args.channels
+    cfg = pkg.PacketConfig(FrameLength=FL, BitDepth=depth, NumChannels=ch)
+    bps = pkg.bytes_per_sample(depth)
+    stride = FL * ch * bps
+
+    # ---- synthetic packets of this rank's shard (seeded stream, packet index = rank*P + i) -------------
+    t0 = time.time()
+    threads = args.gen_threads or max(1, host_threads() // max(1, min(world, 8)))
+    b = synth.gen_batch(cfg, P, profile=synth.PROFILE_MUSIC, first_index=rank * P, threads=threads)
+    gen_s = time.time() - t0
+    frames_total = int(b.frames.astype(np.int64).sum())
+    samples = frames_total * ch
+    alg_bytes = b.compressed_bytes + frames_total * ch * bps  # packet bytes in + PCM bytes out
+
+    d_blob = torch.from_numpy(b.blob).to(dev)
+    d_off = torch.from_numpy(b.offsets.astype(np.int64)).to(dev)
+    d_sz = torch.from_numpy(b.sizes.astype(np.int32)).to(dev)
+    d_out = torch.zeros((P, stride), dtype=torch.uint8, device=dev)
+    d_fr = torch.zeros(P, dtype=torch.int32, device=dev)
+    d_st = torch.full((P,), -1, dtype=torch.int32, device=dev)
+    dec = pkg.NewPacketDecoder(cfg, local_rank)
+    dec.reserve(P)
+
+    def step():
+        dec.decode_batch_device(d_blob.data_ptr(), d_off.data_ptr(), d_sz.data_ptr(), P, d_out.data_ptr(), stride,
+                                d_fr.data_ptr(), d_st.data_ptr(), sync=False)
+
+    def fence():
+        dec.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    dec.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kms = dec.kernel_times_ms(min(args.steps, 64))
+    kernel_ms = float(np.mean(kms)) if len(kms) else float("nan")
+
+    # ---- bit-exactness at full size: decode(encode(pcm)) == pcm, frame counts, status -------------------
+    bit_exact = None
+    if not args.no_verify:
+        ok = int(d_st.abs().sum().item()) == 0
+        ok = ok and bool(np.array_equal(d_fr.cpu().numpy().astype(np.uint32), b.frames))
+        chunk = 8192
+        for lo in range(0, P, chunk):
+            exp = torch.from_numpy(b.pcm[lo:lo + chunk]).to(dev)
+            ok = ok and bool(torch.equal(d_out[lo:lo + chunk], exp))
+            del exp
+        bit_exact = ok
+        if world > 1:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            bit_exact = bool(t.item())
+
+    # ---- CPU baseline: the oracle (a C port of the reference algorithm) on the host cores, N=1 only -----
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle  # cpu_baseline leg only
+        ocfg = oracle.make_config(FL, depth, ch)
+        cores = host_threads()
+        sample_n = min(P, 65536)
+        t0 = time.perf_counter()
+        _, cf, cs = oracle.decode_batch(ocfg, b.blob, b.offsets[:sample_n], b.sizes[:sample_n], threads=cores,
+                                        want_output=False)
+        cpu_s = time.perf_counter() - t0
+        cpu_samples = int(cf.astype(np.int64).sum()) * ch
+        t0 = time.perf_counter()
+        one_n = min(sample_n, 4096)
+        _, cf1, _ = oracle.decode_batch(ocfg, b.blob, b.offsets[:one_n], b.sizes[:one_n], threads=1,
+                                        want_output=False)
+        one_s = time.perf_counter() - t0
+        cpu = {"value": round(cpu_samples / cpu_s / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+               "sample": "first %d packets of the same batch, %d threads, static partition, %.2f s wall "
+                         "(%.1f core-s)" % (sample_n, cores, cpu_s, cpu_s * cores),
+               "single_thread_value": round(int(cf1.astype(np.int64).sum()) * ch / one_s / 1e6, 2),
+               "all_ok": bool((cs == 0).all())}
+
+    if rank == 0:
+        value = samples * world * args.steps / elapsed / 1e6
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms else None
+        line = {
+            "metric": "Msamples/s decoded (16-bit stereo, 4096-frame packets)" if (depth, ch, FL) == (16, 2, 4096)
+            else "Msamples/s decoded (%d-bit %d-ch, %d-frame packets)" % (depth, ch, FL),
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "%d packets/GPU x %d-bit %d-ch %d-frame ALAC, music-like synthetic, "
+                                   "device-resident in/out" % (P, depth, ch, FL),
+                       "packets_per_gpu": P, "samples_per_step_per_gpu": samples,
+                       "compression_ratio": round(b.compressed_bytes / max(1, frames_total * ch * bps), 4),
+                       "sharding": "independent packet ranges, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None,
+                         "traffic": None, "kernel": "alac_decode_lanes", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "cpu_baseline": cpu, "bit_exact": bit_exact, "gen_seconds": round(gen_s, 2),
+        }
+        if cpu:
+            line["gpu_over_cpu"] = round(value / cpu["value"], 2)
+        print(json.dumps(line), flush=True)
+    dec.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if bit_exact is False:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

@@ -157,6 +157,12 @@ int alacgpu_reserve(alacgpu_decoder* dec, size_t n_packets);
  * HIP events on the handle's stream (valid after a sync). Used by bench.py's roofline. */
 int alacgpu_last_kernel_ms(alacgpu_decoder* dec, float* ms);
 
+/* Per-launch kernel durations: every decode launch is bracketed by a HIP event pair on the handle's
+ * stream (ring of 64). alacgpu_kernel_times synchronizes the stream and returns the durations of the
+ * min(max_n, launches since reset, 64) most recent launches, oldest first. */
+int alacgpu_timing_reset(alacgpu_decoder* dec);
+int alacgpu_kernel_times(alacgpu_decoder* dec, float* ms, size_t max_n, size_t* n_out);
+
 /* The handle's hipStream_t as an opaque pointer (for callers that enqueue copies). */
 void* alacgpu_stream(alacgpu_decoder* dec);
 

@@ -61,7 +61,13 @@ struct alac_oracle {
     int64_t out_len;
 };
 
+#ifdef ORACLE_TRACE_PANIC
+#include <stdio.h>
+#include <execinfo.h>
+#define GO_PANIC(d) do { void* bt_[8]; int n_ = backtrace(bt_, 8); fprintf(stderr, "go panic at oracle line %d\n", __LINE__); backtrace_symbols_fd(bt_, n_, 2); longjmp((d)->panic_jmp, 1); } while (0)
+#else
 #define GO_PANIC(d) longjmp((d)->panic_jmp, 1)
+#endif
 
 /* ---- BitBuffer (bitbuffer.go) ------------------------------------------------------- */
 /* Read: bitbuffer.go:55-69. Buf[Pos:Pos+3:Pos+3] panics unless Pos+3 <= len(Buf). */
@@ -729,6 +735,10 @@ static int32_t decode_packet_into(alac_oracle* d, bitbuf* bits, uint32_t* ns_out
             }
             case ELEM_CPE: {
                 if (chan_idx + 2 > num_chan) goto done;
+                /* DOCUMENTED DEVIATION: a pair mapped to the last output slot (only reachable with an
+                 * element order that does not match NumChannels) makes the reference write outside
+                 * the frame and panic on a full frame; oracle and kernel both call it malformed. */
+                if (offsets[chan_idx] + 2 > num_chan) GO_PANIC(d);
                 uint32_t ns;
                 int32_t st = decode_cpe(d, bits, offsets[chan_idx], num_chan, num_samples, &ns);
                 if (st) return st | (ALACGPU_CTX_CPE << 8);
@@ -764,6 +774,9 @@ alac_oracle* alac_oracle_create(const alacgpu_config* cfg) {
      * outside 1..8 index-panics on first use (decoder.go:140); rejected here up front. */
     if (bytes_per_sample(cfg->bit_depth) == 0) return NULL;
     if (cfg->num_channels < 1 || cfg->num_channels > 8) return NULL;
+    /* FrameLength 0: every compressed element panics at out[0] = pc1[0] (predictor.go:53);
+     * rejected up front like the channel count (include/alacgpu.h, ALACGPU_E_CONFIG). */
+    if (cfg->frame_length == 0) return NULL;
     alac_oracle* d = (alac_oracle*)calloc(1, sizeof(*d));
     if (!d) return NULL;
     d->cfg = *cfg;

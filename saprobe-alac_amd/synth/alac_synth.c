@@ -68,17 +68,20 @@ typedef struct {
 } bitw;
 
 static void bw_put(bitw* w, uint32_t val, uint32_t nbits) {
-    for (uint32_t i = nbits; i-- > 0;) {
-        size_t byte = (size_t)(w->bitpos >> 3);
-        if (byte >= w->cap) {
-            w->overflow = 1;
-            return;
-        }
-        uint32_t bit = (val >> i) & 1u;
-        if ((w->bitpos & 7) == 0) w->buf[byte] = 0;
-        w->buf[byte] |= (uint8_t)(bit << (7 - (w->bitpos & 7)));
-        w->bitpos++;
+    if (nbits == 0) return;
+    if (nbits < 32) val &= (1u << nbits) - 1u;
+    size_t byte = (size_t)(w->bitpos >> 3);
+    uint32_t used = (uint32_t)(w->bitpos & 7);
+    if (byte + 8 > w->cap) { /* need room for the widest spill */
+        w->overflow = 1;
+        return;
     }
+    /* merge into a 40-bit big-endian window starting at `byte` */
+    uint64_t acc = used ? ((uint64_t)(w->buf[byte] >> (8 - used)) << (8 - used)) << 32 : 0;
+    acc |= (uint64_t)val << (40 - used - nbits);
+    uint32_t total = used + nbits;
+    for (uint32_t i = 0; i * 8 < total; i++) w->buf[byte + i] = (uint8_t)(acc >> (32 - 8 * i));
+    w->bitpos += nbits;
 }
 static void bw_put_ones(bitw* w, uint32_t n) {
     while (n >= 16) {
@@ -411,17 +414,35 @@ static void gen_music(uint64_t seed, const alacgpu_config* cfg, uint32_t num_fra
             chph[c][j] = 0.3 * u01(&s);
         }
     double lo = -ldexp(1.0, depth - 1), hi = full;
+    /* oscillators by complex rotation: state (cs,sn) of channel c, partial j */
+    double rc[6], rs[6], cs[8][6], sn[8][6];
+    for (int j = 0; j < 6; j++) {
+        double w0 = 6.283185307179586 * f[j] / rate;
+        rc[j] = cos(w0);
+        rs[j] = sin(w0);
+        for (int c = 0; c < nch; c++) {
+            cs[c][j] = cos(ph[j] + chph[c][j]);
+            sn[c][j] = sin(ph[j] + chph[c][j]);
+        }
+    }
     for (uint32_t i = 0; i < num_frames; i++) {
-        double t = (double)i / rate;
         /* AR(2) low-passed noise shared by all channels + a smaller independent part per channel */
-        double e = (u01(&s) + u01(&s) + u01(&s) - 1.5) * 2.0;
+        uint64_t r0 = splitmix64(&s);
+        double e = ((double)(r0 & 0xfffff) + (double)((r0 >> 20) & 0xfffff) + (double)((r0 >> 40) & 0xfffff)) *
+                       (2.0 / 1048576.0) - 3.0;
         double n0 = 1.6 * common[0] - 0.68 * common[1] + 0.08 * e;
         common[1] = common[0];
         common[0] = n0;
         for (int c = 0; c < nch; c++) {
             double x = 0;
-            for (int j = 0; j < 6; j++) x += w[c][j] * a[j] * sin(6.283185307179586 * f[j] * t + ph[j] + chph[c][j]);
-            double ei = (u01(&s) + u01(&s) - 1.0) * 2.0;
+            for (int j = 0; j < 6; j++) {
+                x += w[c][j] * a[j] * sn[c][j];
+                double ncs = cs[c][j] * rc[j] - sn[c][j] * rs[j];
+                sn[c][j] = sn[c][j] * rc[j] + cs[c][j] * rs[j];
+                cs[c][j] = ncs;
+            }
+            uint64_t r1 = splitmix64(&s);
+            double ei = ((double)(r1 & 0xffffff) + (double)((r1 >> 24) & 0xffffff)) * (2.0 / 16777216.0) - 2.0;
             double ni = 1.2 * chs[c][0] - 0.4 * chs[c][1] + 0.2 * ei;
             chs[c][1] = chs[c][0];
             chs[c][0] = ni;

@@ -1,0 +1,161 @@
+"""Shared fixtures. `-m "not gpu"` runs here on CPU; `-m gpu` runs on a real MI355X.
+
+CPU suite: oracle vs golden vectors, round trips, the kernel's lane logic compiled for the host
+(tests/host_sim) vs the oracle, host-side API, C-ABI symbol check, gloo sharding.
+GPU suite: parity of the HIP path with the oracle, always through the C ABI.
+"""
+import ctypes
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The product package (its directory name has a hyphen)."""
+    return importlib.import_module("saprobe-alac_amd")
+
+
+@pytest.fixture(scope="session")
+def synth():
+    m = importlib.import_module("saprobe-alac_amd.synth")
+    m.build()
+    return m
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def lane_sim(oracle):
+    """Host build of csrc/alac_lane.h (test-only; see tests/host_sim/lane_sim.cpp)."""
+    d = os.path.join(ROOT, "tests", "host_sim")
+    so = os.path.join(d, "liblane_sim.so")
+    srcs = [os.path.join(d, "lane_sim.cpp"), os.path.join(ROOT, "saprobe-alac_amd", "csrc", "alac_lane.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-fwrapv", "-fPIC", "-std=c++17", "-Wno-unknown-pragmas", "-shared",
+                               "-o", so, srcs[0]])
+    L = ctypes.CDLL(so)
+    vp = ctypes.c_void_p
+    L.lane_sim_decode_batch.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp, vp, ctypes.c_int]
+
+    def run(cfg, blob, offsets, sizes):
+        n = len(offsets)
+        stride = (oracle.frame_bytes(cfg) + 15) // 16 * 16
+        out = np.zeros((n, stride), np.uint8)
+        fr = np.zeros(n, np.uint32)
+        st = np.zeros(n, np.int32)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        sizes = np.ascontiguousarray(sizes, np.uint32)
+        L.lane_sim_decode_batch(ctypes.byref(cfg), blob.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, n,
+                                out.ctypes.data, stride, fr.ctypes.data, st.ctypes.data, 1)
+        return out, fr, st
+
+    return run
+
+
+def pack_packets(packets, pad=16):
+    """List of packet bytes -> (blob, offsets[n], sizes[n]) in the device blob layout."""
+    offs, sizes, buf = [], [], bytearray()
+    for q in packets:
+        offs.append(len(buf))
+        sizes.append(len(q))
+        buf += q
+        buf += bytes(pad)
+        while len(buf) % 16:
+            buf.append(0)
+    buf += bytes(64)
+    return (np.frombuffer(bytes(buf), np.uint8).copy(), np.array(offs, np.uint64), np.array(sizes, np.uint32))
+
+
+def mutate_packets(batch, rng, n_out):
+    """Corrupt valid packets: bit flips, truncation, header damage, garbage, constant tails."""
+    pk = []
+    for _ in range(n_out):
+        src = bytearray(batch.packet(int(rng.integers(batch.n))))
+        mode = int(rng.integers(6))
+        if mode == 0:
+            for _ in range(int(rng.integers(1, 8))):
+                k = int(rng.integers(len(src)))
+                src[k] ^= 1 << int(rng.integers(8))
+        elif mode == 1:
+            src = src[:int(rng.integers(0, len(src) + 1))]
+        elif mode == 2:
+            for _ in range(int(rng.integers(1, 4))):
+                k = int(rng.integers(min(len(src), 12)))
+                src[k] = int(rng.integers(256))
+        elif mode == 3:
+            src = bytearray(rng.integers(0, 256, int(rng.integers(0, 200)), dtype=np.uint8).tobytes())
+        elif mode == 4:
+            src = src[:int(rng.integers(1, len(src) + 1))]
+            k = int(rng.integers(len(src)))
+            src[k] ^= 0xff
+        else:
+            k = int(rng.integers(len(src)))
+            src[k:] = bytes([0xff if rng.integers(2) else 0]) * (len(src) - k)
+        pk.append(bytes(src))
+    return pk
+
+
+def assert_same_decode(cfg, ref, got, bpf, what=""):
+    """(out, frames, status) triples must agree: status, frame count, and PCM bytes of the frames."""
+    o1, f1, s1 = ref
+    o2, f2, s2 = got
+    assert np.array_equal(s1, s2), "%s status differs at %s" % (what, np.nonzero(s1 != s2)[0][:8])
+    assert np.array_equal(f1, f2), "%s frame count differs at %s" % (what, np.nonzero(f1 != f2)[0][:8])
+    for i in range(len(f1)):
+        nb = int(f1[i]) * bpf
+        if not np.array_equal(o1[i, :nb], o2[i, :nb]):
+            bad = np.nonzero(o1[i, :nb] != o2[i, :nb])[0]
+            raise AssertionError("%s packet %d: PCM differs at byte %d (of %d)" % (what, i, bad[0], nb))
+
+
+@pytest.fixture(scope="session")
+def helpers():
+    class H:
+        pass
+
+    H.pack_packets = staticmethod(pack_packets)
+    H.mutate_packets = staticmethod(mutate_packets)
+    H.assert_same_decode = staticmethod(assert_same_decode)
+    return H
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu_decoder_factory(pkg):
+    """PacketDecoder factory for the gpu-marked tests; fails loudly if the extension is missing."""
+    if not _have_gpu():
+        pytest.fail("gpu-marked test on a machine without a GPU")
+    assert os.path.exists(pkg.lib_path()), "libalacgpu.so missing: build() did not run"
+
+    def make(cfg_like):
+        c = pkg.PacketConfig(FrameLength=cfg_like.frame_length, BitDepth=cfg_like.bit_depth,
+                             NumChannels=cfg_like.num_channels, PB=cfg_like.pb, MB=cfg_like.mb, KB=cfg_like.kb,
+                             MaxRun=cfg_like.max_run, SampleRate=cfg_like.sample_rate)
+        return pkg.NewPacketDecoder(c, 0)
+
+    return make

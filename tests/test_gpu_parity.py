@@ -1,0 +1,155 @@
+"""Parity of the HIP path with the oracle on a real MI355X — every call goes through the C ABI
+(include/alacgpu.h via the ctypes mirror). Bit-exact: PCM bytes, frame counts and status words."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _gpu_decode(dec, b_blob, offsets, sizes):
+    """Host entry (alacgpu_decode_batch): contiguous offsets[n+1] are rebuilt from the padded layout."""
+    pk = [b_blob[int(o):int(o) + int(s)].tobytes() for o, s in zip(offsets, sizes)]
+    offs = np.zeros(len(pk) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(p) for p in pk], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(pk) + b"\0", np.uint8)
+    return dec.decode_batch(blob, offs)
+
+
+def test_known_answer_packets_on_gpu(pkg):
+    k = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+    c = k["config_common"]
+    for v in k["vectors"]:
+        cfg = pkg.PacketConfig(FrameLength=v["frame_length"], BitDepth=c["bit_depth"],
+                               NumChannels=v["num_channels"], PB=c["pb"], MB=c["mb"], KB=c["kb"], MaxRun=c["max_run"])
+        with pkg.NewPacketDecoder(cfg) as dec:
+            pcm = dec.DecodePacket(bytes.fromhex(v["packet"].replace(" ", "")))
+            assert pcm.hex().upper() == v["pcm"].upper(), v["name"]
+            f = dec.Format()
+            assert (f.SampleRate, f.BitDepth, f.Channels) == (44100, 16, v["num_channels"])
+
+
+def test_golden_packets_on_gpu(pkg):
+    g = json.load(open(os.path.join(HERE, "golden", "golden_packets.json")))
+    c = g["config_common"]
+    decs = {}
+    for v in g["vectors"]:
+        key = (v["frame_length"], v["bit_depth"], v["num_channels"])
+        if key not in decs:
+            decs[key] = pkg.NewPacketDecoder(pkg.PacketConfig(FrameLength=key[0], BitDepth=key[1], NumChannels=key[2],
+                                                              PB=c["pb"], MB=c["mb"], KB=c["kb"], MaxRun=c["max_run"]))
+        dec = decs[key]
+        try:
+            pcm = dec.DecodePacket(bytes.fromhex(v["packet"]))
+            st = 0
+        except pkg.ErrDecode as e:
+            pcm, st = b"", e.status
+        assert st == v["status"], v
+        assert hashlib.sha256(pcm).hexdigest() == v["pcm_sha256"]
+    for d in decs.values():
+        d.close()
+
+
+CONFIGS = [(16, 2, 4096), (24, 2, 4096), (16, 1, 4096), (24, 8, 1024), (20, 2, 512), (32, 2, 512), (16, 6, 300),
+           (20, 3, 300), (32, 1, 100), (16, 7, 40), (24, 4, 77), (16, 5, 33), (16, 2, 1)]
+
+
+@pytest.mark.parametrize("depth,ch,fl", CONFIGS)
+def test_batch_matches_oracle(pkg, oracle, synth, helpers, gpu_decoder_factory, depth, ch, fl):
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    with gpu_decoder_factory(cfg) as dec:
+        for prof, n in ((synth.PROFILE_MUSIC, 200), (synth.PROFILE_NOISE, 70), (synth.PROFILE_QUIET, 70),
+                        (synth.PROFILE_STRESS, 330)):
+            b = synth.gen_batch(cfg, n, profile=prof, threads=8)
+            ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=8)
+            got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
+            helpers.assert_same_decode(cfg, ref, got, bpf, "profile %d" % prof)
+            if prof != synth.PROFILE_STRESS and depth in (16, 24) or prof == synth.PROFILE_MUSIC:
+                # lossless: the decoder gives back the source PCM (tests/conformance_test.go:282-291)
+                assert (got[2] == 0).all()
+                for i in range(b.n):
+                    nb = int(b.frames[i]) * bpf
+                    assert np.array_equal(got[0][i, :nb], b.pcm[i, :nb])
+
+
+@pytest.mark.parametrize("depth,ch,fl,kb", [(16, 2, 256, 14), (24, 2, 128, 14), (16, 1, 64, 14), (24, 8, 32, 14),
+                                            (20, 3, 50, 14), (32, 2, 64, 14), (16, 2, 256, 0), (16, 2, 8, 255)])
+def test_corrupt_packets_match_oracle_and_do_not_poison_the_batch(pkg, oracle, synth, helpers, gpu_decoder_factory,
+                                                                  depth, ch, fl, kb):
+    cfg = oracle.make_config(fl, depth, ch, kb=kb)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    rng = np.random.default_rng(99 + depth + ch + kb)
+    with gpu_decoder_factory(cfg) as dec:
+        b = synth.gen_batch(cfg, 64, profile=synth.PROFILE_MUSIC, threads=8)
+        good = [b.packet(i) for i in range(b.n)]
+        bad = helpers.mutate_packets(b, rng, 700)
+        mixed = []
+        for i, p in enumerate(bad):  # interleave intact packets: a bad neighbour must not affect them
+            mixed.append(p)
+            if i % 5 == 0:
+                mixed.append(good[i % len(good)])
+        blob, offs, sizes = helpers.pack_packets(mixed)
+        ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=8)
+        got = _gpu_decode(dec, blob, offs, sizes)
+        helpers.assert_same_decode(cfg, ref, got, bpf, "fuzz")
+        assert (ref[2] != 0).sum() > 100 and (ref[2] == 0).sum() > 100
+
+
+def test_ragged_and_empty_batches(pkg, oracle, synth, helpers, gpu_decoder_factory):
+    cfg = oracle.make_config(512, 16, 2)
+    with gpu_decoder_factory(cfg) as dec:
+        assert dec.DecodePackets([]) == []
+        for n in (1, 63, 64, 65, 129):  # around the 64-packet wave
+            b = synth.gen_batch(cfg, n, threads=4)
+            ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes)
+            helpers.assert_same_decode(cfg, ref, _gpu_decode(dec, b.blob, b.offsets, b.sizes), 4, "n=%d" % n)
+        res = dec.DecodePackets([b.packet(0), b"", bytes([0xE0]), b.packet(1)[:20]])
+        assert res[0] == b.pcm[0, :int(b.frames[0]) * 4].tobytes()
+        assert isinstance(res[1], pkg.ErrDecode) and res[1].sentinel == pkg.ErrBitstreamOverrun
+        assert res[2] == bytes(512 * 4)
+        assert isinstance(res[3], pkg.ErrDecode)
+        with pytest.raises(pkg.ErrDecode):
+            dec.DecodePacket(b"")
+
+
+def test_device_resident_entry_full_size_round_trip(pkg, synth, oracle, gpu_decoder_factory):
+    """BASELINE config b: 4096 x 16-bit stereo 4096-frame packets through alacgpu_decode_batch_device,
+    checked by the size-independent property decode(encode(pcm)) == pcm, plus a slice against the oracle."""
+    import torch
+    cfg = oracle.make_config(4096, 16, 2)
+    n = 4096
+    b = synth.gen_batch(cfg, n, threads=16)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(b.blob).to(dev)
+    d_off = torch.from_numpy(b.offsets.astype(np.int64)).to(dev)
+    d_sz = torch.from_numpy(b.sizes.astype(np.int32)).to(dev)
+    stride = 4096 * 4
+    d_out = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    d_fr = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with gpu_decoder_factory(cfg) as dec:
+        dec.decode_batch_device(d_blob.data_ptr(), d_off.data_ptr(), d_sz.data_ptr(), n, d_out.data_ptr(), stride,
+                                d_fr.data_ptr(), d_st.data_ptr(), sync=True)
+        assert dec.last_kernel_ms() > 0
+    assert int(d_st.abs().sum()) == 0
+    assert np.array_equal(d_fr.cpu().numpy().astype(np.uint32), b.frames)
+    assert torch.equal(d_out.cpu(), torch.from_numpy(b.pcm))
+    ref = oracle.decode_batch(cfg, b.blob, b.offsets[:256], b.sizes[:256], threads=8)
+    assert np.array_equal(ref[0], d_out[:256].cpu().numpy())
+
+
+def test_24bit_shift_and_8ch_full_frames(pkg, synth, oracle, helpers, gpu_decoder_factory):
+    """BASELINE configs c and d at reduced batch: 24-bit stereo with shift buffer; 7.1 24-bit."""
+    for ch, n in ((2, 512), (8, 256)):
+        cfg = oracle.make_config(4096, 24, ch)
+        b = synth.gen_batch(cfg, n, threads=16)
+        with gpu_decoder_factory(cfg) as dec:
+            got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
+        assert (got[2] == 0).all() and np.array_equal(got[1], b.frames)
+        assert np.array_equal(got[0], b.pcm)

@@ -1,0 +1,34 @@
+"""The kernel's per-lane state machine (csrc/alac_lane.h, compiled for the host by tests/host_sim)
+against the oracle: valid streams of every shape, then corrupted ones (status words must agree too)."""
+import numpy as np
+import pytest
+
+CONFIGS = [(16, 2, 4096), (24, 2, 1024), (16, 1, 512), (24, 8, 256), (20, 3, 300), (32, 2, 512), (16, 5, 33),
+           (32, 1, 100), (20, 2, 64), (16, 7, 40), (24, 4, 77), (16, 2, 1)]
+
+
+@pytest.mark.parametrize("depth,ch,fl", CONFIGS)
+def test_lane_matches_oracle_on_valid_streams(oracle, synth, lane_sim, helpers, depth, ch, fl):
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    for prof in (synth.PROFILE_MUSIC, synth.PROFILE_NOISE, synth.PROFILE_QUIET, synth.PROFILE_STRESS):
+        b = synth.gen_batch(cfg, 96, profile=prof, threads=4)
+        ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=4)
+        got = lane_sim(cfg, b.blob, b.offsets, b.sizes)
+        helpers.assert_same_decode(cfg, ref, got, bpf, "profile %d" % prof)
+
+
+@pytest.mark.parametrize("depth,ch,fl,kb", [(16, 2, 256, 14), (24, 2, 128, 14), (16, 1, 64, 14), (24, 8, 32, 14),
+                                            (20, 3, 50, 14), (32, 2, 64, 14), (16, 5, 33, 14), (16, 2, 256, 0),
+                                            (24, 6, 16, 3), (16, 2, 8, 255), (32, 8, 5, 14)])
+def test_lane_matches_oracle_on_corrupt_packets(oracle, synth, lane_sim, helpers, depth, ch, fl, kb):
+    cfg = oracle.make_config(fl, depth, ch, kb=kb)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    rng = np.random.default_rng(depth * 1000 + ch * 10 + kb)
+    for prof in (synth.PROFILE_MUSIC, synth.PROFILE_STRESS):
+        b = synth.gen_batch(cfg, 48, profile=prof, threads=4)
+        blob, offs, sizes = helpers.pack_packets(helpers.mutate_packets(b, rng, 400))
+        ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=4)
+        got = lane_sim(cfg, blob, offs, sizes)
+        helpers.assert_same_decode(cfg, ref, got, bpf, "fuzz profile %d" % prof)
+        assert len(np.unique(ref[2])) > 3  # the corpus really reaches several error classes
