@@ -192,6 +192,15 @@ def lib():
         if not os.path.exists(so):
             raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); this package has no CPU decode path" % so)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
+        # /opt/rocm's). If torch is going to be used in this process it must be loaded FIRST so that
+        # libalacgpu.so binds to the runtime torch initialises; loaded the other way round the process
+        # ends up with two runtimes and torch.cuda.is_available() turns False. The library only needs
+        # the stable hip_4.2 symbol set, so either runtime serves it.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(so)
         for name, (res, args) in _EXPORTS.items():
             fn = getattr(L, name)
