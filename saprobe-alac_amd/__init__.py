@@ -113,6 +113,16 @@ class PacketConfig(ctypes.Structure):
         super().__init__(FrameLength, BitDepth, NumChannels, PB, MB, KB, 0, MaxRun, MaxFrameBytes, AvgBitRate,
                          SampleRate)
 
+    # C-side field names (alacgpu_config) as read-only aliases
+    frame_length = property(lambda s: s.FrameLength)
+    bit_depth = property(lambda s: s.BitDepth)
+    num_channels = property(lambda s: s.NumChannels)
+    pb = property(lambda s: s.PB)
+    mb = property(lambda s: s.MB)
+    kb = property(lambda s: s.KB)
+    max_run = property(lambda s: s.MaxRun)
+    sample_rate = property(lambda s: s.SampleRate)
+
 
 class PCMFormat(ctypes.Structure):
     """PCMFormat (format.go:20-24)."""

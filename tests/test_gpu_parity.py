@@ -69,7 +69,7 @@ def test_batch_matches_oracle(pkg, oracle, synth, helpers, gpu_decoder_factory, 
             ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=8)
             got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
             helpers.assert_same_decode(cfg, ref, got, bpf, "profile %d" % prof)
-            if prof != synth.PROFILE_STRESS and depth in (16, 24) or prof == synth.PROFILE_MUSIC:
+            if fl > 8 and prof != synth.PROFILE_STRESS:  # fl <= order: the reference panics in the warm-up
                 # lossless: the decoder gives back the source PCM (tests/conformance_test.go:282-291)
                 assert (got[2] == 0).all()
                 for i in range(b.n):
