@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--out-stride-pad", type=int, default=0, help="extra bytes between PCM slots (experiments)")
     return ap.parse_args()
 
 
@@ -85,7 +86,7 @@ def main():
     P, FL, depth, ch = args.packets, args.frame_length, args.depth, args.channels
     cfg = pkg.PacketConfig(FrameLength=FL, BitDepth=depth, NumChannels=ch)
     bps = pkg.bytes_per_sample(depth)
-    stride = FL * ch * bps
+    stride = FL * ch * bps + args.out_stride_pad
 
     # ---- synthetic packets of this rank's shard (seeded stream, packet index = rank*P + i) -------------
     t0 = time.time()
@@ -139,7 +140,7 @@ def main():
         chunk = 8192
         for lo in range(0, P, chunk):
             exp = torch.from_numpy(b.pcm[lo:lo + chunk]).to(dev)
-            ok = ok and bool(torch.equal(d_out[lo:lo + chunk], exp))
+            ok = ok and bool(torch.equal(d_out[lo:lo + chunk, :exp.shape[1]], exp))
             del exp
         bit_exact = ok
         if world > 1:
