@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--profile", type=int, default=0, help="synth profile (0 = SURVEY 8d music model)")
     ap.add_argument("--out-stride-pad", type=int, default=0, help="extra bytes between PCM slots (experiments)")
     return ap.parse_args()
 
@@ -91,7 +92,7 @@ def main():
     # ---- synthetic packets of this rank's shard (seeded stream, packet index = rank*P + i) -------------
     t0 = time.time()
     threads = args.gen_threads or max(1, host_threads() // max(1, min(world, 8)))
-    b = synth.gen_batch(cfg, P, profile=synth.PROFILE_MUSIC, first_index=rank * P, threads=threads)
+    b = synth.gen_batch(cfg, P, profile=args.profile, first_index=rank * P, threads=threads)
     gen_s = time.time() - t0
     frames_total = int(b.frames.astype(np.int64).sum())
     samples = frames_total * ch

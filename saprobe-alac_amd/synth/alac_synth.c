@@ -534,7 +534,7 @@ void alac_synth_params(const alacgpu_config* cfg, int profile, uint64_t seed, al
             ep->partial = (uint8_t)((r2 >> 29) & 1 & (r % 11 == 0));
         } else {
             uint32_t oc = r % 100;
-            int order = oc < 30 ? 4 : oc < 60 ? 6 : oc < 90 ? 8 : oc < 95 ? 5 : 12;
+            int order = oc < 30 ? 4 : oc < 60 ? 6 : oc < 90 ? 8 : (oc < 95 || profile == ALAC_SYNTH_PROFILE_MUSIC_LE8) ? 5 : 12;
             ep->order_u = ep->order_v = (uint8_t)order;
             ep->den_shift = 9;
             ep->pb_factor = 4;

@@ -19,7 +19,8 @@ enum {
     ALAC_SYNTH_PROFILE_MUSIC = 0,  /* throughput distribution, SURVEY.md §8d */
     ALAC_SYNTH_PROFILE_NOISE = 1,  /* full-scale white noise: escapes */
     ALAC_SYNTH_PROFILE_QUIET = 2,  /* tiny residuals + silence: zero runs */
-    ALAC_SYNTH_PROFILE_STRESS = 3  /* parity-only: random everything */
+    ALAC_SYNTH_PROFILE_STRESS = 3, /* parity-only: random everything */
+    ALAC_SYNTH_PROFILE_MUSIC_LE8 = 4 /* MUSIC without the 5 % order-12 packets (kernel experiments) */
 };
 enum {
     ALAC_SYNTH_FLAG_LEADING_FIL = 1, /* FIL element before the first audio element */
