@@ -188,7 +188,7 @@ def main():
                        "sharding": "independent packet ranges, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None,
-                         "traffic": None, "kernel": "alac_decode_lanes", "kernel_ms": round(kernel_ms, 4),
+                         "traffic": None, "kernel": "alac_decode", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu, "bit_exact": bit_exact, "gen_seconds": round(gen_s, 2),
         }

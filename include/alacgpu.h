@@ -103,9 +103,10 @@ typedef enum alacgpu_stage {
 #define ALACGPU_E_DECODE   -4  /* alacgpu_decode_packet only: packet failed, *status_out holds the word */
 
 /* Every packet in a device-resident blob must be followed by at least this many
- * zero bytes (the reference pads each packet with 4, bitbuffer.go:33; the kernel
- * prefetches a little further). alacgpu_decode_batch re-packs host input itself. */
-#define ALACGPU_PACKET_PAD 16
+ * zero bytes (the reference pads each packet with 4, bitbuffer.go:33; the kernel's
+ * bitstream cache prefetches two dwords further). Packet starts need no alignment
+ * (16 bytes is what alacgpu_decode_batch produces when it re-packs host input). */
+#define ALACGPU_PACKET_PAD 32
 
 typedef struct alacgpu_decoder alacgpu_decoder;
 

@@ -34,7 +34,7 @@ __all__ = [
     "ErrConfig", "ErrDecode", "AlacError", "build", "lib", "lib_path",
 ]
 
-PACKET_PAD = 16  # ALACGPU_PACKET_PAD
+PACKET_PAD = 32  # ALACGPU_PACKET_PAD
 
 
 # ---- errors: errors.go:22-34 and internal/alac/errors.go:24-33 -------------------------------------
@@ -162,7 +162,7 @@ def lib_path():
 def build(force=False):
     """Compile csrc/alacgpu.hip for gfx950 (hipcc cross-compiles without a GPU)."""
     so = lib_path()
-    srcs = [os.path.join(_CSRC, f) for f in ("alacgpu.hip", "alac_lane.h")] + [
+    srcs = [os.path.join(_CSRC, f) for f in ("alacgpu.hip", "alac_wave.h")] + [
         os.path.join(_HERE, "..", "include", "alacgpu.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _CSRC, "libalacgpu.so"], stdout=subprocess.DEVNULL)

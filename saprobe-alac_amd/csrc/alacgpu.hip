@@ -1,14 +1,18 @@
 /*
- * alacgpu.hip — gfx950 batch ALAC decode kernel + the C ABI of include/alacgpu.h.
+ * alacgpu.hip — gfx950 batch ALAC decode kernels + the C ABI of include/alacgpu.h.
  *
  * Replaces the reference's per-packet hot path (decoder.go:133-207 -> internal/alac golomb.go,
- * predictor.go, matrix.go) with one HIP kernel over a batch of independent packets. There is no
- * host decode path in this library: every decode entry launches the kernel.
+ * predictor.go, matrix.go) with HIP kernels over a batch of independent packets. There is no host decode
+ * path in this library: every decode entry launches the kernels.
  *
- * Kernel shape: one 64-lane wavefront per 64 packets, one workgroup per wavefront
- * (no cross-lane traffic, so nothing to share in LDS); lanes run the state machine of alac_lane.h
- * in lock step. HBM traffic per packet: compressed bytes in, PCM bytes out, plus the U-channel
- * hand-off tile (frame_length x 64 x int32 per wave, row-coalesced, written once and read once).
+ * One decode = four launches on the handle's stream:
+ *   alac_classify  one thread per packet: predictor-order class from the first element header (10 bytes read)
+ *   alac_plan      one thread: class histogram -> packet/wave ranges (slow classes get the lowest block ids)
+ *   alac_scatter   one thread per packet: counting-sort scatter into the lane permutation
+ *   alac_decode    one 64-lane wavefront per 64 same-class packets, lanes in lock step (alac_wave.h);
+ *                  PCM is staged per lane in LDS and written back as whole 128-B lines.
+ * HBM traffic per packet: compressed bytes in, PCM bytes out, plus the U-channel hand-off tile
+ * (frame_length x 64 x int32 per wave, row-coalesced, written once and read once).
  */
 #include <hip/hip_runtime.h>
 
@@ -18,30 +22,166 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
-#include <vector>
 
 #define ALAC_DEV __device__ __forceinline__
-#include "alac_lane.h"
+#define ALAC_MUL24(a, b) __mul24((int)(a), (int)(b))
+#include "alac_wave.h"
 
 namespace {
 
 constexpr uint32_t kWave = 64;
 constexpr uint32_t kTimingSlots = 64;
+constexpr uint32_t kRowStride = 65; /* dwords per lane row in LDS: odd stride = conflict-free column access */
+constexpr uint32_t kRing = 64;      /* dwords of PCM a lane row holds (two 128-B chunks) */
+constexpr uint32_t kFallbackSlots = 64;
+
+/* device-side launch plan, rebuilt by every decode */
+struct Plan {
+    uint32_t count[alac::NUM_CLASSES];      /* packets per class */
+    uint32_t pkt_start[alac::NUM_CLASSES];  /* first index in perm[] */
+    uint32_t wave_start[alac::NUM_CLASSES]; /* first block id */
+    uint32_t cursor[alac::NUM_CLASSES];     /* scatter cursors */
+    uint32_t total_waves;
+};
+
+/* ---- gfx950 wave policy for alac::decode_wave --------------------------------------------------------- */
+struct GpuWave {
+    uint32_t* rows;            /* LDS [64][kRowStride] */
+    unsigned long long* optr;  /* LDS [64]: PCM slot of each lane's packet */
+    int32_t* u_tile;           /* HBM: this lane's column of the wave's U hand-off tile */
+    int32_t* g_tile;           /* HBM: this lane's column of the wave's fall-back tile */
+    uint8_t* my_out;
+    uint32_t lane, wcnt, flushed;
+
+    ALAC_DEV bool any(bool p) const { return __ballot(p) != 0ull; }
+    ALAC_DEV uint32_t max_u32(uint32_t v) const {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+            v = t > v ? t : v;
+        }
+        return v;
+    }
+    ALAC_DEV void st_begin(uint8_t* out) {
+        my_out = out;
+        optr[lane] = (unsigned long long)reinterpret_cast<uintptr_t>(out);
+        wcnt = flushed = 0;
+    }
+    ALAC_DEV void st_push(uint32_t v) {
+        rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
+        ++wcnt;
+    }
+    /* Collective. Rows that just completed a 32-dword chunk are written out as 128-B lines: store
+     * instruction k covers packets 8k..8k+7, eight lanes x 16 B per packet. Lock step makes `flushed`
+     * identical in all full lanes. */
+    ALAC_DEV void st_step() {
+        const bool full = (wcnt - flushed) >= 32u;
+        const unsigned long long mask = __ballot(full);
+        if (mask == 0ull) return;
+        __builtin_amdgcn_wave_barrier();
+        const int first = __ffsll((long long)mask) - 1;
+        const uint32_t fl = (uint32_t)__shfl((int)flushed, first, 64);
+        const uint32_t col0 = fl & (kRing - 1u);
+        const uint32_t piece = lane & 7u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t q = 8u * k + (lane >> 3);
+            if ((mask >> q) & 1ull) {
+                const uint32_t* r = rows + q * kRowStride + col0 + piece * 4u;
+                const uint4 v = make_uint4(r[0], r[1], r[2], r[3]);
+                uint8_t* dst = reinterpret_cast<uint8_t*>((uintptr_t)optr[q]) + ((size_t)fl + piece * 4u) * 4u;
+                *reinterpret_cast<uint4*>(dst) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (full) flushed += 32u;
+    }
+    ALAC_DEV uint32_t st_finish() {
+        for (uint32_t w = flushed; w < wcnt; ++w)
+            *reinterpret_cast<uint32_t*>(my_out + (size_t)w * 4u) = rows[lane * kRowStride + (w & (kRing - 1u))];
+        flushed = wcnt;
+        return wcnt;
+    }
+    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * kWave; }
+    ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * kWave; }
+};
+
+__global__ void __launch_bounds__(256)
+alac_classify(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+              const uint32_t* __restrict__ sizes, uint32_t n, uint8_t* __restrict__ cls, Plan* plan) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = alac::classify_packet(blob + offsets[i], sizes[i]);
+    cls[i] = (uint8_t)c;
+    atomicAdd(&plan->count[c], 1u);
+}
+
+__global__ void alac_plan(Plan* plan) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    /* slowest class first: its waves must start first, the kernel ends when the last wave does */
+    uint32_t p = 0, w = 0;
+    for (int c = alac::NUM_CLASSES - 1; c >= 0; --c) {
+        plan->pkt_start[c] = p;
+        plan->wave_start[c] = w;
+        plan->cursor[c] = 0;
+        p += plan->count[c];
+        w += (plan->count[c] + kWave - 1) / kWave;
+    }
+    plan->total_waves = w;
+}
+
+__global__ void __launch_bounds__(256)
+alac_scatter(const uint8_t* __restrict__ cls, uint32_t n, Plan* plan, uint32_t* __restrict__ perm) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = cls[i];
+    perm[plan->pkt_start[c] + atomicAdd(&plan->cursor[c], 1u)] = i;
+}
 
 __global__ void __launch_bounds__(kWave)
-alac_decode_lanes(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
-                  const uint32_t* __restrict__ sizes, uint32_t n_packets, uint8_t* __restrict__ out,
-                  uint64_t out_stride, uint32_t* __restrict__ frames_out, int32_t* __restrict__ status,
-                  int32_t* __restrict__ scratch) {
+alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+            const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+            uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
+            int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g) {
+    __shared__ uint32_t s_rows[kWave * kRowStride];
+    __shared__ unsigned long long s_optr[kWave];
+
+    const uint32_t b = blockIdx.x;
+    if (b >= plan->total_waves) return;
+    uint32_t cls = 0;
+#pragma unroll
+    for (int c = 0; c < alac::NUM_CLASSES; ++c)
+        if (b >= plan->wave_start[c] && b < plan->wave_start[c] + (plan->count[c] + kWave - 1) / kWave) cls = (uint32_t)c;
     const uint32_t lane = threadIdx.x;
-    const uint64_t pkt = (uint64_t)blockIdx.x * kWave + lane;
-    if (pkt >= n_packets) return;
-    int32_t* scr = scratch + (uint64_t)blockIdx.x * cfg.frame_length * kWave + lane;
+    const uint32_t idx = (b - plan->wave_start[cls]) * kWave + lane;
+    const bool live = idx < plan->count[cls];
+    const uint32_t pkt = live ? perm[plan->pkt_start[cls] + idx] : 0u;
+
+    GpuWave wv;
+    wv.rows = s_rows;
+    wv.optr = s_optr;
+    wv.u_tile = scratch_u + (size_t)b * cfg.frame_length * kWave + lane;
+    wv.g_tile = scratch_g + (size_t)b * kFallbackSlots * kWave + lane;
+    wv.my_out = nullptr;
+    wv.lane = lane;
+    wv.wcnt = wv.flushed = 0;
+
+    const uint8_t* p = blob + (live ? offsets[pkt] : 0ull);
+    const uint32_t size = live ? sizes[pkt] : 0u;
+    uint8_t* o = out + (size_t)pkt * out_stride;
     uint32_t frames = 0;
-    const int32_t st = alac::decode_lane<kWave>(cfg, blob + offsets[pkt], sizes[pkt], out + pkt * out_stride, scr,
-                                                &frames);
-    frames_out[pkt] = frames;
-    status[pkt] = st;
+    int32_t st;
+    /* cls is wave-uniform (one class per block): a scalar branch picks the variant */
+    switch (__builtin_amdgcn_readfirstlane(cls)) {
+        case alac::CLASS_NA4: st = alac::decode_wave<GpuWave, 4, false>(wv, cfg, live, p, size, o, &frames); break;
+        case alac::CLASS_NA6: st = alac::decode_wave<GpuWave, 6, false>(wv, cfg, live, p, size, o, &frames); break;
+        case alac::CLASS_NA8: st = alac::decode_wave<GpuWave, 8, false>(wv, cfg, live, p, size, o, &frames); break;
+        default: st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, o, &frames); break;
+    }
+    if (live) {
+        frames_out[pkt] = frames;
+        status[pkt] = st;
+    }
 }
 
 thread_local char g_err[512] = "";
@@ -122,12 +262,25 @@ struct alacgpu_decoder {
     hipStream_t stream;
     hipEvent_t ev_start[kTimingSlots], ev_stop[kTimingSlots]; /* ring of per-launch event pairs */
     uint64_t launches;                                       /* since the last timing reset */
-    DevBuf scratch;                                  /* U hand-off tiles */
+    DevBuf scratch_u, scratch_g, plan, cls, perm;            /* kernel workspace */
     DevBuf d_blob, d_offsets, d_sizes, d_out, d_frames, d_status; /* host-entry staging */
     HostBuf h_blob, h_meta;
 };
 
 namespace {
+
+size_t max_waves(size_t n) { return (n + kWave - 1) / kWave + alac::NUM_CLASSES; }
+
+int reserve_workspace(alacgpu_decoder* dec, size_t n) {
+    const size_t waves = max_waves(n);
+    int rc;
+    if ((rc = dec->scratch_u.ensure(waves * dec->cfg.frame_length * kWave * sizeof(int32_t)))) return rc;
+    if ((rc = dec->scratch_g.ensure(waves * kFallbackSlots * kWave * sizeof(int32_t)))) return rc;
+    if ((rc = dec->plan.ensure(sizeof(Plan)))) return rc;
+    if ((rc = dec->cls.ensure(n ? n : 1))) return rc;
+    if ((rc = dec->perm.ensure((n ? n : 1) * sizeof(uint32_t)))) return rc;
+    return ALACGPU_E_OK;
+}
 
 int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offsets, const uint32_t* d_sizes,
            size_t n, uint8_t* d_out, size_t out_stride, uint32_t* d_frames, int32_t* d_status) {
@@ -136,18 +289,23 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
         set_err("batch too large");
         return ALACGPU_E_ARG;
     }
-    const uint32_t waves = (uint32_t)((n + kWave - 1) / kWave);
-    int rc = dec->scratch.ensure((size_t)waves * dec->cfg.frame_length * kWave * sizeof(int32_t));
+    int rc = reserve_workspace(dec, n);
     if (rc) return rc;
     alac::DevCfg c = dec->dev_cfg;
-    c.fast16s = (dec->cfg.bit_depth == 16 && dec->cfg.num_channels == 2 && out_stride % 16 == 0 &&
-                 (reinterpret_cast<uintptr_t>(d_out) % 16) == 0)
-                    ? 1u
-                    : 0u;
+    c.aligned16 = (out_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(d_out) % 16) == 0) ? 1u : 0u;
+    Plan* plan = (Plan*)dec->plan.p;
+    const uint32_t nb = (uint32_t)((n + 255) / 256);
+    HIP_TRY(hipMemsetAsync(plan, 0, sizeof(Plan), dec->stream));
+    hipLaunchKernelGGL(alac_classify, dim3(nb), dim3(256), 0, dec->stream, d_blob, d_offsets, d_sizes, (uint32_t)n,
+                       (uint8_t*)dec->cls.p, plan);
+    hipLaunchKernelGGL(alac_plan, dim3(1), dim3(1), 0, dec->stream, plan);
+    hipLaunchKernelGGL(alac_scatter, dim3(nb), dim3(256), 0, dec->stream, (const uint8_t*)dec->cls.p, (uint32_t)n, plan,
+                       (uint32_t*)dec->perm.p);
     const uint32_t slot = (uint32_t)(dec->launches % kTimingSlots);
     HIP_TRY(hipEventRecord(dec->ev_start[slot], dec->stream));
-    hipLaunchKernelGGL(alac_decode_lanes, dim3(waves), dim3(kWave), 0, dec->stream, c, d_blob, d_offsets, d_sizes,
-                       (uint32_t)n, d_out, (uint64_t)out_stride, d_frames, d_status, (int32_t*)dec->scratch.p);
+    hipLaunchKernelGGL(alac_decode, dim3((uint32_t)max_waves(n)), dim3(kWave), 0, dec->stream, c, d_blob, d_offsets,
+                       d_sizes, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride, d_frames,
+                       d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(dec->ev_stop[slot], dec->stream));
     dec->launches++;
@@ -207,7 +365,11 @@ void alacgpu_destroy(alacgpu_decoder* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     (void)hipStreamSynchronize(d->stream);
-    d->scratch.release();
+    d->scratch_u.release();
+    d->scratch_g.release();
+    d->plan.release();
+    d->cls.release();
+    d->perm.release();
     d->d_blob.release();
     d->d_offsets.release();
     d->d_sizes.release();
@@ -237,8 +399,7 @@ size_t alacgpu_frame_bytes(const alacgpu_decoder* d) { return d ? d->frame_bytes
 int alacgpu_reserve(alacgpu_decoder* d, size_t n) {
     if (!d) return ALACGPU_E_ARG;
     HIP_TRY(hipSetDevice(d->device));
-    const size_t waves = (n + kWave - 1) / kWave;
-    return d->scratch.ensure(waves * d->cfg.frame_length * kWave * sizeof(int32_t));
+    return reserve_workspace(d, n);
 }
 
 int alacgpu_decode_batch_device(alacgpu_decoder* d, const uint8_t* d_blob, const uint64_t* d_offsets,
@@ -296,7 +457,7 @@ int alacgpu_decode_batch(alacgpu_decoder* d, const uint8_t* blob, const uint64_t
         memcpy(hb + h_off[i], blob + offsets[i], h_sz[i]);
         memset(hb + h_off[i] + h_sz[i], 0, end - (size_t)h_off[i] - h_sz[i]);
     }
-    /* keep the device output rows 16-byte aligned so the wide-store path is taken */
+    /* keep the device output rows 16-byte aligned so the LDS-staged wide-store path is taken */
     const size_t d_stride = (d->frame_bytes + 15u) & ~(size_t)15u;
     if ((rc = d->d_blob.ensure(total))) return rc;
     if ((rc = d->d_offsets.ensure(n * sizeof(uint64_t)))) return rc;
@@ -345,17 +506,6 @@ int alacgpu_decode_packet(alacgpu_decoder* d, const uint8_t* packet, size_t pack
     return ALACGPU_E_OK;
 }
 
-int alacgpu_last_kernel_ms(alacgpu_decoder* d, float* ms) {
-    size_t got = 0;
-    int rc = alacgpu_kernel_times(d, ms, 1, &got);
-    if (rc) return rc;
-    if (got == 0) {
-        set_err("no kernel has been launched on this handle since the last timing reset");
-        return ALACGPU_E_ARG;
-    }
-    return ALACGPU_E_OK;
-}
-
 int alacgpu_timing_reset(alacgpu_decoder* d) {
     if (!d) return ALACGPU_E_ARG;
     d->launches = 0;
@@ -377,6 +527,17 @@ int alacgpu_kernel_times(alacgpu_decoder* d, float* ms, size_t max_n, size_t* n_
     return ALACGPU_E_OK;
 }
 
+int alacgpu_last_kernel_ms(alacgpu_decoder* d, float* ms) {
+    size_t got = 0;
+    int rc = alacgpu_kernel_times(d, ms, 1, &got);
+    if (rc) return rc;
+    if (got == 0) {
+        set_err("no kernel has been launched on this handle since the last timing reset");
+        return ALACGPU_E_ARG;
+    }
+    return ALACGPU_E_OK;
+}
+
 void* alacgpu_stream(alacgpu_decoder* d) { return d ? (void*)d->stream : nullptr; }
 
 int alacgpu_synchronize(alacgpu_decoder* d) {
@@ -388,6 +549,6 @@ int alacgpu_synchronize(alacgpu_decoder* d) {
 
 const char* alacgpu_last_error(void) { return g_err; }
 
-const char* alacgpu_version(void) { return "alacgpu 0.1.0 gfx950"; }
+const char* alacgpu_version(void) { return "alacgpu 0.2.0 gfx950"; }
 
 } /* extern "C" */

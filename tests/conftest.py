@@ -44,33 +44,38 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def lane_sim(oracle):
-    """Host build of csrc/alac_lane.h (test-only; see tests/host_sim/lane_sim.cpp)."""
+    """Host build of csrc/alac_wave.h (test-only; see tests/host_sim/lane_sim.cpp)."""
     d = os.path.join(ROOT, "tests", "host_sim")
     so = os.path.join(d, "liblane_sim.so")
-    srcs = [os.path.join(d, "lane_sim.cpp"), os.path.join(ROOT, "saprobe-alac_amd", "csrc", "alac_lane.h")]
+    srcs = [os.path.join(d, "lane_sim.cpp"), os.path.join(ROOT, "saprobe-alac_amd", "csrc", "alac_wave.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-fwrapv", "-fPIC", "-std=c++17", "-Wno-unknown-pragmas", "-shared",
                                "-o", so, srcs[0]])
     L = ctypes.CDLL(so)
     vp = ctypes.c_void_p
-    L.lane_sim_decode_batch.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp, vp, ctypes.c_int]
+    L.lane_sim_decode_batch.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp, vp, ctypes.c_int,
+                                        ctypes.c_int, vp]
 
-    def run(cfg, blob, offsets, sizes):
+    def run(cfg, blob, offsets, sizes, variant=-1, stride_pad=0, want_classes=False):
         n = len(offsets)
-        stride = (oracle.frame_bytes(cfg) + 15) // 16 * 16
+        stride = (oracle.frame_bytes(cfg) + 15) // 16 * 16 + stride_pad
         out = np.zeros((n, stride), np.uint8)
+        classes = np.zeros(n, np.uint32)
         fr = np.zeros(n, np.uint32)
         st = np.zeros(n, np.int32)
         offsets = np.ascontiguousarray(offsets, np.uint64)
         sizes = np.ascontiguousarray(sizes, np.uint32)
         L.lane_sim_decode_batch(ctypes.byref(cfg), blob.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, n,
-                                out.ctypes.data, stride, fr.ctypes.data, st.ctypes.data, 1)
+                                out.ctypes.data, stride, fr.ctypes.data, st.ctypes.data, 1, variant,
+                                classes.ctypes.data)
+        if want_classes:
+            return out, fr, st, classes
         return out, fr, st
 
     return run
 
 
-def pack_packets(packets, pad=16):
+def pack_packets(packets, pad=32):
     """List of packet bytes -> (blob, offsets[n], sizes[n]) in the device blob layout."""
     offs, sizes, buf = [], [], bytearray()
     for q in packets:

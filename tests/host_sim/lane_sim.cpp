@@ -1,10 +1,10 @@
 /*
- * lane_sim.cpp — TEST-ONLY host build of the kernel's per-lane state machine.
+ * lane_sim.cpp — TEST-ONLY host build of the kernel's decode logic.
  *
- * Compiles saprobe-alac_amd/csrc/alac_lane.h (the exact text the gfx950 kernel is built from) with
- * g++ and runs it one "lane" at a time, so the decode LOGIC can be compared with the oracle in the
- * CPU test-suite (-m "not gpu"), where no GPU exists. It lives under tests/, is never linked into
- * libalacgpu.so and is not a decode path of the product.
+ * Compiles saprobe-alac_amd/csrc/alac_wave.h (the exact text the gfx950 kernel is built from) with g++
+ * and a one-lane wave policy, so the decode LOGIC can be compared with the oracle in the CPU test-suite
+ * (-m "not gpu"), where no GPU exists. It lives under tests/, is never linked into libalacgpu.so and is not
+ * a decode path of the product.
  */
 #include <cstdint>
 #include <cstdlib>
@@ -12,11 +12,40 @@
 #include <vector>
 
 #define ALAC_DEV inline
-#include "../../saprobe-alac_amd/csrc/alac_lane.h"
+#include "../../saprobe-alac_amd/csrc/alac_wave.h"
 
+namespace {
+
+/* one-lane wave: collectives are identities, the stager writes straight to the PCM slot */
+struct HostWave {
+    std::vector<int32_t> u_tile, g_tile;
+    uint8_t* st_out = nullptr;
+    uint32_t st_cnt = 0;
+    explicit HostWave(uint32_t frame_length) : u_tile(frame_length ? frame_length : 1), g_tile(64) {}
+    bool any(bool p) const { return p; }
+    uint32_t max_u32(uint32_t v) const { return v; }
+    void st_begin(uint8_t* out) {
+        st_out = out;
+        st_cnt = 0;
+    }
+    void st_push(uint32_t v) {
+        memcpy(st_out + 4u * (size_t)st_cnt, &v, 4);
+        ++st_cnt;
+    }
+    void st_step() {}
+    uint32_t st_finish() { return st_cnt; }
+    int32_t* u_row(uint32_t i) { return &u_tile[i]; }
+    int32_t* g_slot(uint32_t k) { return &g_tile[k]; }
+};
+
+}  // namespace
+
+/* variant: 0..3 = force that class's kernel variant (any class must decode any packet correctly);
+ *          -1   = pick by classify_packet like the GPU pre-pass does. classes_out (may be null) gets the class. */
 extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* blob, const uint64_t* offsets,
                                      const uint32_t* sizes, size_t n, uint8_t* out, size_t out_stride,
-                                     uint32_t* frames_out, int32_t* status, int poison) {
+                                     uint32_t* frames_out, int32_t* status, int poison, int variant,
+                                     uint32_t* classes_out) {
     alac::DevCfg dc{};
     dc.frame_length = cfg->frame_length;
     dc.bit_depth = cfg->bit_depth;
@@ -25,19 +54,26 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
     dc.mb = cfg->mb;
     dc.kb = cfg->kb;
     dc.bps = cfg->bit_depth == 16 ? 2 : cfg->bit_depth == 32 ? 4 : 3;
-    dc.fast16s = (cfg->bit_depth == 16 && cfg->num_channels == 2 && out_stride % 16 == 0 &&
-                  (reinterpret_cast<uintptr_t>(out) % 16) == 0)
-                     ? 1u
-                     : 0u;
-    std::vector<int32_t> scr(cfg->frame_length ? cfg->frame_length : 1);
+    dc.aligned16 = (out_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0) ? 1u : 0u;
+    HostWave wv(cfg->frame_length);
     for (size_t i = 0; i < n; i++) {
         /* the kernel never relies on scratch or output contents: poison them */
         if (poison) {
-            memset(scr.data(), 0x5a, scr.size() * sizeof(int32_t));
+            memset(wv.u_tile.data(), 0x5a, wv.u_tile.size() * sizeof(int32_t));
+            memset(wv.g_tile.data(), 0x5a, wv.g_tile.size() * sizeof(int32_t));
             memset(out + i * out_stride, 0xa5, out_stride);
         }
-        status[i] = alac::decode_lane<1>(dc, blob + offsets[i], sizes[i], out + i * out_stride, scr.data(),
-                                         &frames_out[i]);
+        const uint8_t* p = blob + offsets[i];
+        uint8_t* o = out + i * out_stride;
+        const uint32_t cls = variant >= 0 ? (uint32_t)variant : alac::classify_packet(p, sizes[i]);
+        if (classes_out) classes_out[i] = cls;
+        frames_out[i] = 0;
+        switch (cls) {
+            case alac::CLASS_NA4: status[i] = alac::decode_wave<HostWave, 4, false>(wv, dc, true, p, sizes[i], o, &frames_out[i]); break;
+            case alac::CLASS_NA6: status[i] = alac::decode_wave<HostWave, 6, false>(wv, dc, true, p, sizes[i], o, &frames_out[i]); break;
+            case alac::CLASS_NA8: status[i] = alac::decode_wave<HostWave, 8, false>(wv, dc, true, p, sizes[i], o, &frames_out[i]); break;
+            default: status[i] = alac::decode_wave<HostWave, 16, true>(wv, dc, true, p, sizes[i], o, &frames_out[i]); break;
+        }
     }
     return 0;
 }

@@ -1,4 +1,4 @@
-"""The kernel's per-lane state machine (csrc/alac_lane.h, compiled for the host by tests/host_sim)
+"""The kernel's decode logic (csrc/alac_wave.h, compiled for the host by tests/host_sim)
 against the oracle: valid streams of every shape, then corrupted ones (status words must agree too)."""
 import numpy as np
 import pytest
@@ -14,8 +14,13 @@ def test_lane_matches_oracle_on_valid_streams(oracle, synth, lane_sim, helpers, 
     for prof in (synth.PROFILE_MUSIC, synth.PROFILE_NOISE, synth.PROFILE_QUIET, synth.PROFILE_STRESS):
         b = synth.gen_batch(cfg, 96, profile=prof, threads=4)
         ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=4)
-        got = lane_sim(cfg, b.blob, b.offsets, b.sizes)
-        helpers.assert_same_decode(cfg, ref, got, bpf, "profile %d" % prof)
+        # every class variant must decode every packet (the order class is a speed choice only) ...
+        for variant in (-1, 0, 1, 2, 3):
+            got = lane_sim(cfg, b.blob, b.offsets, b.sizes, variant=variant)
+            helpers.assert_same_decode(cfg, ref, got, bpf, "profile %d variant %d" % (prof, variant))
+        # ... and so must the unaligned-output path (direct stores instead of the LDS stager)
+        got = lane_sim(cfg, b.blob, b.offsets, b.sizes, stride_pad=4)
+        helpers.assert_same_decode(cfg, ref, got, bpf, "profile %d unaligned" % prof)
 
 
 @pytest.mark.parametrize("depth,ch,fl,kb", [(16, 2, 256, 14), (24, 2, 128, 14), (16, 1, 64, 14), (24, 8, 32, 14),
@@ -29,6 +34,7 @@ def test_lane_matches_oracle_on_corrupt_packets(oracle, synth, lane_sim, helpers
         b = synth.gen_batch(cfg, 48, profile=prof, threads=4)
         blob, offs, sizes = helpers.pack_packets(helpers.mutate_packets(b, rng, 400))
         ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=4)
-        got = lane_sim(cfg, blob, offs, sizes)
-        helpers.assert_same_decode(cfg, ref, got, bpf, "fuzz profile %d" % prof)
+        for variant in (-1, 0, 3):
+            got = lane_sim(cfg, blob, offs, sizes, variant=variant)
+            helpers.assert_same_decode(cfg, ref, got, bpf, "fuzz profile %d variant %d" % (prof, variant))
         assert len(np.unique(ref[2])) > 3  # the corpus really reaches several error classes
