@@ -52,6 +52,7 @@ struct GpuWave {
     int32_t* g_tile;           /* HBM: this lane's column of the wave's fall-back tile */
     uint8_t* my_out;
     uint32_t lane, wcnt, flushed;
+    uint32_t ppw;              /* packets (= live lanes) per wave; also the row stride of the HBM tiles */
 
     ALAC_DEV bool any(bool p) const { return __ballot(p) != 0ull; }
     ALAC_DEV uint32_t max_u32(uint32_t v) const {
@@ -83,8 +84,8 @@ struct GpuWave {
         const uint32_t fl = (uint32_t)__shfl((int)flushed, first, 64);
         const uint32_t col0 = fl & (kRing - 1u);
         const uint32_t piece = lane & 7u;
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t groups = (ppw + 7u) >> 3;
+        for (uint32_t k = 0; k < groups; ++k) {
             const uint32_t q = 8u * k + (lane >> 3);
             if ((mask >> q) & 1ull) {
                 const uint32_t* r = rows + q * kRowStride + col0 + piece * 4u;
@@ -102,8 +103,8 @@ struct GpuWave {
         flushed = wcnt;
         return wcnt;
     }
-    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * kWave; }
-    ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * kWave; }
+    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * ppw; }
+    ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * ppw; }
 };
 
 __global__ void __launch_bounds__(256)
@@ -116,7 +117,7 @@ alac_classify(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ off
     atomicAdd(&plan->count[c], 1u);
 }
 
-__global__ void alac_plan(Plan* plan) {
+__global__ void alac_plan(Plan* plan, uint32_t ppw) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     /* slowest class first: its waves must start first, the kernel ends when the last wave does */
     uint32_t p = 0, w = 0;
@@ -125,7 +126,7 @@ __global__ void alac_plan(Plan* plan) {
         plan->wave_start[c] = w;
         plan->cursor[c] = 0;
         p += plan->count[c];
-        w += (plan->count[c] + kWave - 1) / kWave;
+        w += (plan->count[c] + ppw - 1) / ppw;
     }
     plan->total_waves = w;
 }
@@ -142,7 +143,8 @@ __global__ void __launch_bounds__(kWave)
 alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
             const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
             uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
-            int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g) {
+            int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g,
+            uint32_t ppw) {
     __shared__ uint32_t s_rows[kWave * kRowStride];
     __shared__ unsigned long long s_optr[kWave];
 
@@ -151,17 +153,18 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     uint32_t cls = 0;
 #pragma unroll
     for (int c = 0; c < alac::NUM_CLASSES; ++c)
-        if (b >= plan->wave_start[c] && b < plan->wave_start[c] + (plan->count[c] + kWave - 1) / kWave) cls = (uint32_t)c;
+        if (b >= plan->wave_start[c] && b < plan->wave_start[c] + (plan->count[c] + ppw - 1) / ppw) cls = (uint32_t)c;
     const uint32_t lane = threadIdx.x;
-    const uint32_t idx = (b - plan->wave_start[cls]) * kWave + lane;
-    const bool live = idx < plan->count[cls];
+    const uint32_t idx = (b - plan->wave_start[cls]) * ppw + lane;
+    const bool live = lane < ppw && idx < plan->count[cls];
     const uint32_t pkt = live ? perm[plan->pkt_start[cls] + idx] : 0u;
 
     GpuWave wv;
     wv.rows = s_rows;
     wv.optr = s_optr;
-    wv.u_tile = scratch_u + (size_t)b * cfg.frame_length * kWave + lane;
-    wv.g_tile = scratch_g + (size_t)b * kFallbackSlots * kWave + lane;
+    wv.u_tile = scratch_u + (size_t)b * cfg.frame_length * ppw + lane;
+    wv.g_tile = scratch_g + (size_t)b * kFallbackSlots * ppw + lane;
+    wv.ppw = ppw;
     wv.my_out = nullptr;
     wv.lane = lane;
     wv.wcnt = wv.flushed = 0;
@@ -269,13 +272,26 @@ struct alacgpu_decoder {
 
 namespace {
 
-size_t max_waves(size_t n) { return (n + kWave - 1) / kWave + alac::NUM_CLASSES; }
+size_t max_waves(size_t n, uint32_t ppw) { return (n + ppw - 1) / ppw + alac::NUM_CLASSES; }
 
-int reserve_workspace(alacgpu_decoder* dec, size_t n) {
-    const size_t waves = max_waves(n);
+/* Packets per wave. The lock-step loop is a dependent chain that one wave issues at ~1 instruction per 4-5
+ * cycles, so the machine is filled by MORE WAVES, not fuller ones: below ~2 resident waves per SIMD a batch is
+ * spread over narrower waves (a half-empty wave costs the same issue slots, but the slots were idle anyway). */
+uint32_t pick_ppw(size_t n) {
+    if (const char* e = getenv("ALACGPU_PPW")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) return (uint32_t)v;
+    }
+    uint32_t ppw = kWave;
+    while (ppw > 1 && n / ppw < 2048) ppw >>= 1;
+    return ppw;
+}
+
+int reserve_workspace(alacgpu_decoder* dec, size_t n, uint32_t ppw) {
+    const size_t waves = max_waves(n, ppw);
     int rc;
-    if ((rc = dec->scratch_u.ensure(waves * dec->cfg.frame_length * kWave * sizeof(int32_t)))) return rc;
-    if ((rc = dec->scratch_g.ensure(waves * kFallbackSlots * kWave * sizeof(int32_t)))) return rc;
+    if ((rc = dec->scratch_u.ensure(waves * dec->cfg.frame_length * ppw * sizeof(int32_t)))) return rc;
+    if ((rc = dec->scratch_g.ensure(waves * kFallbackSlots * ppw * sizeof(int32_t)))) return rc;
     if ((rc = dec->plan.ensure(sizeof(Plan)))) return rc;
     if ((rc = dec->cls.ensure(n ? n : 1))) return rc;
     if ((rc = dec->perm.ensure((n ? n : 1) * sizeof(uint32_t)))) return rc;
@@ -289,7 +305,8 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
         set_err("batch too large");
         return ALACGPU_E_ARG;
     }
-    int rc = reserve_workspace(dec, n);
+    const uint32_t ppw = pick_ppw(n);
+    int rc = reserve_workspace(dec, n, ppw);
     if (rc) return rc;
     alac::DevCfg c = dec->dev_cfg;
     c.aligned16 = (out_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(d_out) % 16) == 0) ? 1u : 0u;
@@ -298,14 +315,14 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
     HIP_TRY(hipMemsetAsync(plan, 0, sizeof(Plan), dec->stream));
     hipLaunchKernelGGL(alac_classify, dim3(nb), dim3(256), 0, dec->stream, d_blob, d_offsets, d_sizes, (uint32_t)n,
                        (uint8_t*)dec->cls.p, plan);
-    hipLaunchKernelGGL(alac_plan, dim3(1), dim3(1), 0, dec->stream, plan);
+    hipLaunchKernelGGL(alac_plan, dim3(1), dim3(1), 0, dec->stream, plan, ppw);
     hipLaunchKernelGGL(alac_scatter, dim3(nb), dim3(256), 0, dec->stream, (const uint8_t*)dec->cls.p, (uint32_t)n, plan,
                        (uint32_t*)dec->perm.p);
     const uint32_t slot = (uint32_t)(dec->launches % kTimingSlots);
     HIP_TRY(hipEventRecord(dec->ev_start[slot], dec->stream));
-    hipLaunchKernelGGL(alac_decode, dim3((uint32_t)max_waves(n)), dim3(kWave), 0, dec->stream, c, d_blob, d_offsets,
+    hipLaunchKernelGGL(alac_decode, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, d_offsets,
                        d_sizes, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride, d_frames,
-                       d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p);
+                       d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(dec->ev_stop[slot], dec->stream));
     dec->launches++;
@@ -399,7 +416,7 @@ size_t alacgpu_frame_bytes(const alacgpu_decoder* d) { return d ? d->frame_bytes
 int alacgpu_reserve(alacgpu_decoder* d, size_t n) {
     if (!d) return ALACGPU_E_ARG;
     HIP_TRY(hipSetDevice(d->device));
-    return reserve_workspace(d, n);
+    return reserve_workspace(d, n, pick_ppw(n));
 }
 
 int alacgpu_decode_batch_device(alacgpu_decoder* d, const uint8_t* d_blob, const uint64_t* d_offsets,
