@@ -1,0 +1,369 @@
+/*
+ * alac_regular.h — the lean wave decoder for REGULAR packets (the overwhelming majority of real streams).
+ *
+ * A packet is regular when classify_regular() accepts it: 16-bit, mono or stereo, its first tag is the one
+ * element that covers the whole frame (SCE/LFE for 1 channel, CPE for 2), compressed, no shift bytes,
+ * mode 0 on both channels, predictor orders in {4,5,6,8} (the reference's unrolled int32-coefficient
+ * predictors, predictor.go:81-93), header inside the packet. Everything else takes decode_wave (alac_wave.h),
+ * which decodes any packet. The two produce identical bytes and status words; which one runs is a speed
+ * choice made per packet by the classifier, and waves are built from packets with the same (numU, numV).
+ *
+ * What "lean" buys: with the orders wave-uniform the predictor is compiled for exactly NA
+ * taps and the warm-up test is scalar; the per-sample step has no data-dependent branch on its common path
+ * (zero-run countdown, the in-range test and dead lanes are selects; only an escape code, the start of a
+ * zero run or an error take the one slow branch); |diff| + rounding is one v_sad_u32 on a sign-biased history;
+ * all products are 24-bit (v_mad_i32_i24 / v_mad_u32_u24), exact because chanBits <= 17 here.
+ */
+#ifndef ALAC_REGULAR_H
+#define ALAC_REGULAR_H
+
+#include "alac_wave.h"
+
+#ifndef ALAC_NOINLINE
+#define ALAC_NOINLINE
+#endif
+#ifndef ALAC_SAD
+/* |a - b| + c on unsigned operands: v_sad_u32 on the GPU */
+#define ALAC_SAD(a, b, c) (((a) > (b) ? (a) - (b) : (b) - (a)) + (c))
+#endif
+#ifndef ALAC_MED3
+#define ALAC_MED3(x, lo, hi) ((x) < (lo) ? (lo) : (x) > (hi) ? (hi) : (x))
+#endif
+
+namespace alac {
+
+constexpr uint32_t KEY_IRREGULAR = 1024; /* sort key of packets for decode_wave; regular: numU*32 + numV */
+constexpr uint32_t NUM_KEYS = 1025;
+
+ALAC_DEV bool regular_order(uint32_t na) { return na == 4 || na == 5 || na == 6 || na == 8; }
+
+/* Sort key of a packet; no entropy decoding, reads only the element header. */
+ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32_t size) {
+    if (cfg.bit_depth != 16 || cfg.num_channels > 2 || cfg.aligned16 == 0 || cfg.kb == 0 ||
+        cfg.frame_length > 65536u || cfg.frame_length <= 8u)
+        return KEY_IRREGULAR;
+    const Bits bits{pkt, size};
+    if (size < 12) return KEY_IRREGULAR;
+    const uint32_t tag = bits.get(0, 3);
+    const bool cpe = cfg.num_channels == 2;
+    if (cpe ? tag != 1 : !(tag == 0 || tag == 3)) return KEY_IRREGULAR;
+    if (bits.get(7, 12) != 0) return KEY_IRREGULAR;
+    const uint32_t hdr = bits.get(19, 4);
+    if (hdr & 7u) return KEY_IRREGULAR; /* shift bytes or escape */
+    uint32_t pos = 23;
+    uint32_t ns = cfg.frame_length;
+    if (hdr >> 3) {
+        ns = bits.get(pos, 32);
+        pos += 32;
+    }
+    if (ns == 0 || ns > cfg.frame_length) return KEY_IRREGULAR;
+    pos += 16; /* mixBits, mixRes */
+    const uint32_t hu = bits.get(pos, 16);
+    const uint32_t nu = hu & 0x1fu;
+    if ((hu >> 12) != 0 || !regular_order(nu)) return KEY_IRREGULAR;
+    pos += 16u + 16u * nu;
+    uint32_t nv = 0;
+    if (cpe) {
+        const uint32_t hv = bits.get(pos, 16);
+        nv = hv & 0x1fu;
+        if ((hv >> 12) != 0 || !regular_order(nv)) return KEY_IRREGULAR;
+        pos += 16u + 16u * nv;
+    }
+    /* header must be wholly inside the packet and the entropy stream must start inside it (anything
+     * else is an error or panic case: decode_wave reports those) */
+    if ((pos >> 3) >= size) return KEY_IRREGULAR;
+    return nu * 32u + nv;
+}
+
+/* FastRd::slide without a branch: the cache moves by 0 or 1 dword (a step consumes <= 32 bits; the slow path
+ * re-seeks), and the look-ahead dword is (re)loaded every step. */
+ALAC_DEV void slide_branchless(FastRd& rd, uint32_t pos) {
+    const uint32_t ni = (pos + rd.bias) >> 5;
+    const bool cross = ni != rd.widx;
+    rd.w0 = cross ? rd.w1 : rd.w0;
+    rd.w1 = cross ? rd.w2 : rd.w1;
+    rd.widx = ni;
+    rd.w2 = FastRd::ld(rd.base + ni + 2);
+}
+
+/* per-lane Golomb + reader state of one channel */
+struct RegLane {
+    FastRd rd;
+    uint32_t pos, mean, zmode, zrem, pb, max_pos;
+    int32_t err;
+};
+
+/* The rare part of DynDecomp (golomb.go:167-247) for one lane: overrun, an escape code, and/or the start of a
+ * zero run. Redoes the sample from its start with the stateless reader; returns the residual. */
+template <class BitsT>
+ALAC_DEV ALAC_NOINLINE int32_t golomb_slow(const BitsT& bits, RegLane& s, uint32_t size, uint32_t kb, uint32_t wb,
+                                           uint32_t chan_bits, uint32_t i, uint32_t ns) {
+    if (s.pos >= s.max_pos) {
+        s.err = ST_OVERRUN; /* golomb.go:168-170 */
+        return 0;
+    }
+    uint32_t m = s.mean >> 9;
+    const uint32_t k = umin(31u - clz32(m + 3u), kb);
+    m = (1u << k) - 1u;
+    const uint32_t w = (uint32_t)(bits.window(s.pos) >> 32);
+    uint32_t n = clz32(~w);
+    if (n >= 9) { /* getStreamBits(bitPos+9, maxSize), golomb.go:184-186,86-108 */
+        const uint32_t gpos = s.pos + 9u;
+        const uint32_t gb = gpos & 7u;
+        const bool five = chan_bits + gb > 32u;
+        if ((gpos >> 3) > size || (five && (gpos >> 3) >= size)) {
+            s.err = ST_MALFORMED;
+            return 0;
+        }
+        n = (uint32_t)(bits.window(gpos) >> (64u - chan_bits)); /* chan_bits is 16 or 17 here */
+        s.pos += 9u + chan_bits;
+    } else {
+        const uint32_t v = (w << (n + 1u)) >> (32u - k);
+        s.pos += n + 1u + k - (v >= 2 ? 0u : 1u);
+        n = v >= 2 ? n * m + v - 1u : n * m;
+    }
+    const uint32_t nd = n + s.zmode;
+    const int32_t half = (int32_t)((nd + 1u) >> 1);
+    const int32_t del = (nd & 1u) ? -half : half;
+    s.mean = s.pb * nd + s.mean - ((s.pb * s.mean) >> 9);
+    if (n > 0xffffu) s.mean = 0xffffu;
+    s.zmode = 0;
+    if ((s.mean << 2) < 512u && i + 1u < ns) { /* golomb.go:223-246 */
+        s.zmode = 1;
+        int32_t k32 = (int32_t)clz32(s.mean) - 24 + (int32_t)((s.mean + 16u) >> 6);
+        if (k32 < 0) k32 = 0;
+        const uint32_t kz = (uint32_t)k32;
+        const uint32_t mz = ((1u << kz) - 1u) & wb;
+        if ((s.pos >> 3) > size) { /* dynGet's read32bit, golomb.go:115 */
+            s.err = ST_MALFORMED;
+            return del;
+        }
+        const uint32_t wz = (uint32_t)(bits.window(s.pos) >> 32);
+        const uint32_t pre = clz32(~wz);
+        uint32_t rl;
+        if (pre >= 9) {
+            rl = (wz << 9) >> 16;
+            s.pos += 25u;
+        } else {
+            const uint32_t val = kz == 0 ? 0u : (wz << (pre + 1u)) >> (32u - kz);
+            s.pos += pre + 1u + kz;
+            if (val < 2) {
+                rl = pre * mz;
+                s.pos -= 1u;
+            } else {
+                rl = pre * mz + val - 1u;
+            }
+        }
+        if ((uint64_t)i + 1u + rl > ns) s.err = ST_SAMPLE_OVERRUN; /* golomb.go:232-234 */
+        s.zrem = rl;
+        if (rl >= 65535u) s.zmode = 0;
+        s.mean = 0;
+    }
+    s.rd.seek(s.pos);
+    return del;
+}
+
+/*
+ * One channel of a regular element, all lanes in lock step. NA = this channel's predictor order (wave-uniform).
+ * LAST: this channel completes the frame (V of a pair, or the mono channel): unmix and emit PCM.
+ */
+template <class W, int NA, bool LAST, bool CPE>
+ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane& s, uint32_t size, uint32_t ns,
+                            uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
+                            uint32_t mix_sh) {
+    constexpr uint32_t BIAS = 0x80000000u;
+    const uint32_t kb = cfg.kb;
+    const uint32_t wb = (1u << kb) - 1u;
+    const uint32_t chan_shift = 32u - chan_bits;
+    const int32_t den_half = den_shift ? (int32_t)(1u << (den_shift - 1u)) : 0;
+    const uint32_t rnd_neg = (1u << den_shift) - 1u;
+
+    int32_t coef[NA];
+    uint32_t hb[NA + 1]; /* hb[j] = out[i-1-j] ^ BIAS: |a - b| of biased values is one unsigned sad */
+#pragma unroll
+    for (int j = 0; j < NA; ++j) coef[j] = (int32_t)(int16_t)bits.get(hdr_pos + 16u + 16u * (uint32_t)j, 16);
+#pragma unroll
+    for (int j = 0; j <= NA; ++j) hb[j] = BIAS;
+    uint32_t held = 0; /* mono: low half of the dword under construction */
+
+    for (uint32_t i = 0; i < n_it; ++i) {
+        const bool on = i < ns && s.err == 0;
+        int32_t u_pre = 0;
+        if (LAST && CPE) u_pre = *wv.u_row(i); /* issued first: its latency hides behind the decode */
+
+        /* ---- one residual (DynDecomp, golomb.go:167-247), common path without branches ---------------------- */
+        const bool inrun = s.zrem != 0;
+        const bool dec = on && !inrun;
+        uint32_t m = s.mean >> 9;
+        const uint32_t k = umin(31u - clz32(m + 3u), kb);
+        m = (1u << k) - 1u;
+        const uint32_t w = s.rd.window(s.pos);
+        const uint32_t pre = clz32(~w);
+        const uint32_t v = (w << ((pre + 1u) & 31u)) >> (32u - k);
+        const bool big = v >= 2;
+        const uint32_t n = pre * m + (big ? v - 1u : 0u);
+        const uint32_t nd = n + s.zmode;
+        uint32_t mean2 = s.pb * nd + s.mean - ((s.pb * s.mean) >> 9); /* golomb.go:215 */
+        if (n > 0xffffu) mean2 = 0xffffu;
+        const bool slow = dec && (s.pos >= s.max_pos || pre >= 9 || ((mean2 << 2) < 512u && i + 1u < ns));
+        const int32_t half = (int32_t)((nd + 1u) >> 1); /* golomb.go:206-209 */
+        int32_t del = (nd & 1u) ? -half : half;
+        if (inrun) del = 0;
+        if (wv.any(slow)) {
+            if (slow) del = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns);
+        }
+        const bool commit = dec && !slow;
+        s.pos = commit ? s.pos + pre + k + (big ? 1u : 0u) : s.pos; /* prefix + 1, then k bits (v >= 2) or k - 1 */
+        s.mean = commit ? mean2 : s.mean;
+        s.zmode = commit ? 0u : s.zmode;
+        s.zrem = (on && inrun) ? s.zrem - 1u : s.zrem;
+        slide_branchless(s.rd, s.pos);
+
+        /* ---- one predictor step (UnpcBlock, predictor.go:45-94) ------------------------------------------------ */
+        int32_t o;
+        if (i <= (uint32_t)NA) { /* scalar test: out[0] = pc1[0], then the warm-up (predictor.go:53,76-79) */
+            o = i == 0 ? del : sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
+        } else {
+            /* unpcBlock4/5/6/8 (predictor.go:99-618): taps walked from the highest down. The adaptation is
+             * sign-normalised: D0 = |del| shrinks by t_j = (NA-j) * ((|d_j| + rnd) >> denShift) tap after tap and
+             * tap j adapts while the running total S_j of the taps above it is still below D0. */
+            const uint32_t topb = hb[NA];
+            const bool neg = del < 0;
+            const uint32_t big_d0 = (uint32_t)(neg ? -del : del);
+            const uint32_t rnd = neg ? rnd_neg : 0u;
+            const int32_t msdir = neg ? 1 : -1;
+            int32_t acc = den_half;
+            uint32_t run = 0;
+#pragma unroll
+            for (int j = NA - 1; j >= 0; --j) {
+                const int32_t d = (int32_t)(topb - hb[j]); /* top - out[i-1-j]; the bias cancels */
+                acc -= ALAC_MUL24(coef[j], d);
+                const int32_t sd = ALAC_MED3(d, -1, 1);
+                const uint32_t q = ALAC_SAD(topb, hb[j], rnd) >> den_shift;
+                const bool act = run < big_d0;
+                coef[j] = act ? coef[j] + ALAC_MUL24(sd, msdir) : coef[j];
+                run += (uint32_t)ALAC_MUL24((int32_t)q, NA - j);
+            }
+            o = sext_cs(del + (int32_t)(topb ^ BIAS) + (acc >> den_shift), chan_shift);
+        }
+#pragma unroll
+        for (int j = NA; j >= 1; --j) hb[j] = hb[j - 1];
+        hb[0] = (uint32_t)o ^ BIAS;
+
+        /* ---- hand-off / unmix / PCM ---------------------------------------------------------------------------- */
+        if (!LAST) {
+            *wv.u_row(i) = o; /* dead lanes write their own unused cell */
+        } else if (CPE) {
+            const int32_t u = u_pre, vv = o;
+            int32_t l, r;
+            if (mix_res != 0) { /* matrix.go:40-41 */
+                l = u + vv - (ALAC_MUL24(mix_res, vv) >> mix_sh);
+                r = l - vv;
+            } else {
+                l = u;
+                r = vv;
+            }
+            wv.st_push_if(((uint32_t)l & 0xffffu) | ((uint32_t)r << 16), on);
+        } else {
+            /* mono 16-bit: two samples per dword (matrix.go:220-232) */
+            if (i & 1u) wv.st_push_if(held | ((uint32_t)o << 16), on);
+            else held = (uint32_t)o & 0xffffu;
+        }
+        if (LAST) wv.st_step(); /* collective */
+    }
+    if (LAST && !CPE) {
+        /* odd frame count: the last sample is still held */
+        if (s.err == 0 && (ns & 1u)) wv.st_tail16((uint16_t)held);
+    }
+}
+
+/* the order switch is scalar: NA is wave-uniform by construction of the waves */
+template <class W, bool LAST, bool CPE>
+ALAC_DEV void regular_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bits, RegLane& s, uint32_t size,
+                               uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
+                               int32_t mix_res, uint32_t mix_sh) {
+    switch (na) {
+        case 4: regular_phase<W, 4, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh); break;
+        case 5: regular_phase<W, 5, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh); break;
+        case 6: regular_phase<W, 6, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh); break;
+        default: regular_phase<W, 8, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh); break;
+    }
+}
+
+/*
+ * decode_regular: every lane of the wave holds a regular packet with the same key = numU*32 + numV (lanes
+ * without a packet pass live = false). Same contract as decode_wave.
+ */
+template <class W>
+ALAC_DEV int32_t decode_regular(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
+                                uint8_t* out, uint32_t* frames_out) {
+    const Bits bits{pkt, size};
+    const bool cpe = cfg.num_channels == 2;
+    const uint32_t na_u = key >> 5, na_v = key & 31u;
+
+    RegLane s;
+    s.rd.base = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(pkt) & ~(uintptr_t)3);
+    s.rd.bias = (uint32_t)(reinterpret_cast<uintptr_t>(pkt) & 3u) * 8u;
+    s.rd.w0 = s.rd.w1 = s.rd.w2 = s.rd.widx = 0;
+    s.err = 0;
+    s.max_pos = size * 8u;
+
+    /* header (accepted by classify_regular, so no error can arise here): decoder.go:213-235, 421-450 */
+    uint32_t pos = 23;
+    uint32_t ns = 0;
+    if (live) {
+        ns = cfg.frame_length;
+        if (bits.get(19, 4) >> 3) {
+            ns = bits.get(pos, 32);
+            pos += 32;
+        }
+    }
+    const int32_t mix_bits = (int32_t)bits.get(pos, 8);
+    const int32_t mix_res = (int32_t)(int8_t)bits.get(pos + 8, 8);
+    const uint32_t mix_sh = (uint32_t)mix_bits > 31u ? 31u : (uint32_t)mix_bits;
+    const uint32_t hdr_u = pos + 16u;
+    const uint32_t hdr_v = hdr_u + 16u + 16u * na_u;
+    const uint32_t hu = bits.get(hdr_u, 16);
+    const uint32_t hv = bits.get(hdr_v, 16);
+    s.pos = cpe ? hdr_v + 16u + 16u * na_v : hdr_v;
+    const uint32_t chan_bits = cfg.bit_depth + (cpe ? 1u : 0u);
+    const uint32_t n_it = wv.max_u32(ns);
+    if (live) wv.st_begin(out);
+
+    /* ---- U (or the mono channel) ---- */
+    s.mean = cfg.mb;
+    s.zmode = 0;
+    s.zrem = 0;
+    s.pb = (cfg.pb * ((hu >> 5) & 7u)) / 4u; /* decoder.go:299 */
+    if (live) s.rd.seek(s.pos);
+    if (cpe) regular_phase_na<W, false, true>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh);
+    else regular_phase_na<W, true, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0);
+    uint32_t err_chan = 0;
+    /* ---- V ---- */
+    if (cpe) {
+        const bool u_failed = s.err != 0;
+        if (!u_failed && ((s.pos >> 3) > size + 4u || (s.pos >> 3) > size)) s.err = ST_MALFORMED; /* DynDecomp entry */
+        const int32_t err_u = s.err;
+        s.mean = cfg.mb;
+        s.zmode = 0;
+        s.zrem = 0;
+        s.pb = (cfg.pb * ((hv >> 5) & 7u)) / 4u;
+        if (live && s.err == 0) s.rd.seek(s.pos);
+        regular_phase_na<W, true, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh);
+        if (err_u == 0 && s.err != 0) err_chan = 1;
+    }
+    if (!live) return 0;
+    (void)wv.st_finish();
+    if (s.err) {
+        *frames_out = 0;
+        if (s.err == ST_MALFORMED) return ST_MALFORMED;
+        const uint32_t stage = cpe ? (uint32_t)(err_chan == 0 ? ALACGPU_STAGE_ENTROPY_U : ALACGPU_STAGE_ENTROPY_V)
+                                   : (uint32_t)ALACGPU_STAGE_ENTROPY;
+        return ALACGPU_STATUS(s.err, cpe ? ALACGPU_CTX_CPE : ALACGPU_CTX_SCE, stage);
+    }
+    *frames_out = ns;
+    return 0;
+}
+
+} /* namespace alac */
+#endif

@@ -24,8 +24,13 @@
 #include <new>
 
 #define ALAC_DEV __device__ __forceinline__
+#define ALAC_NOINLINE
 #define ALAC_MUL24(a, b) __mul24((int)(a), (int)(b))
+/* written so that instruction selection picks v_sad_u32 and v_med3_i32 */
+#define ALAC_SAD(a, b, c) ((max((uint32_t)(a), (uint32_t)(b)) - min((uint32_t)(a), (uint32_t)(b))) + (uint32_t)(c))
+#define ALAC_MED3(x, lo, hi) min(max((int32_t)(x), (int32_t)(lo)), (int32_t)(hi))
 #include "alac_wave.h"
+#include "alac_regular.h"
 
 namespace {
 
@@ -36,11 +41,17 @@ constexpr uint32_t kRing = 64;      /* dwords of PCM a lane row holds (two 128-B
 constexpr uint32_t kFallbackSlots = 64;
 
 /* device-side launch plan, rebuilt by every decode */
+/* sort keys: 0..1023 regular packets (numU*32 + numV, alac_regular.h); 1024+c irregular packets of
+ * predictor class c (alac_wave.h). A wave holds packets of ONE key. */
+constexpr uint32_t kKeys = 1024 + alac::NUM_CLASSES;
 struct Plan {
-    uint32_t count[alac::NUM_CLASSES];      /* packets per class */
-    uint32_t pkt_start[alac::NUM_CLASSES];  /* first index in perm[] */
-    uint32_t wave_start[alac::NUM_CLASSES]; /* first block id */
-    uint32_t cursor[alac::NUM_CLASSES];     /* scatter cursors */
+    uint32_t count[kKeys];     /* packets per key */
+    uint32_t pkt_start[kKeys]; /* first index in perm[] */
+    uint32_t cursor[kKeys];    /* scatter cursors */
+    /* compact list of the non-empty keys in dispatch order (slowest first) */
+    uint32_t nk;
+    uint32_t list_key[kKeys];
+    uint32_t list_wave0[kKeys]; /* first block id */
     uint32_t total_waves;
 };
 
@@ -72,6 +83,13 @@ struct GpuWave {
         rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
         ++wcnt;
     }
+    /* branch-free form: a lane that is not `on` rewrites its next free slot and does not advance */
+    ALAC_DEV void st_push_if(uint32_t v, bool on) {
+        rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
+        wcnt += on ? 1u : 0u;
+    }
+    /* 16-bit tail after the last whole dword (mono, odd frame count) */
+    ALAC_DEV void st_tail16(uint16_t h) { *reinterpret_cast<uint16_t*>(my_out + (size_t)wcnt * 4u) = h; }
     /* Collective. Rows that just completed a 32-dword chunk are written out as 128-B lines: store
      * instruction k covers packets 8k..8k+7, eight lanes x 16 B per packet. Lock step makes `flushed`
      * identical in all full lanes. */
@@ -108,35 +126,44 @@ struct GpuWave {
 };
 
 __global__ void __launch_bounds__(256)
-alac_classify(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
-              const uint32_t* __restrict__ sizes, uint32_t n, uint8_t* __restrict__ cls, Plan* plan) {
+alac_classify(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+              const uint32_t* __restrict__ sizes, uint32_t n, uint16_t* __restrict__ keys, Plan* plan) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t c = alac::classify_packet(blob + offsets[i], sizes[i]);
-    cls[i] = (uint8_t)c;
-    atomicAdd(&plan->count[c], 1u);
+    const uint8_t* p = blob + offsets[i];
+    uint32_t key = alac::classify_regular(cfg, p, sizes[i]);
+    if (key == alac::KEY_IRREGULAR) key = 1024u + alac::classify_packet(p, sizes[i]);
+    keys[i] = (uint16_t)key;
+    atomicAdd(&plan->count[key], 1u);
 }
 
 __global__ void alac_plan(Plan* plan, uint32_t ppw) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    /* slowest class first: its waves must start first, the kernel ends when the last wave does */
-    uint32_t p = 0, w = 0;
-    for (int c = alac::NUM_CLASSES - 1; c >= 0; --c) {
-        plan->pkt_start[c] = p;
-        plan->wave_start[c] = w;
-        plan->cursor[c] = 0;
-        p += plan->count[c];
-        w += (plan->count[c] + ppw - 1) / ppw;
+    /* highest key first: irregular packets, then the longest predictors. The kernel ends when its last wave
+     * does, so the slowest waves take the lowest block ids and start first. */
+    uint32_t p = 0, w = 0, nk = 0;
+    for (int k = (int)kKeys - 1; k >= 0; --k) {
+        const uint32_t c = plan->count[k];
+        plan->pkt_start[k] = p;
+        plan->cursor[k] = 0;
+        if (c) {
+            plan->list_key[nk] = (uint32_t)k;
+            plan->list_wave0[nk] = w;
+            ++nk;
+            p += c;
+            w += (c + ppw - 1) / ppw;
+        }
     }
+    plan->nk = nk;
     plan->total_waves = w;
 }
 
 __global__ void __launch_bounds__(256)
-alac_scatter(const uint8_t* __restrict__ cls, uint32_t n, Plan* plan, uint32_t* __restrict__ perm) {
+alac_scatter(const uint16_t* __restrict__ keys, uint32_t n, Plan* plan, uint32_t* __restrict__ perm) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t c = cls[i];
-    perm[plan->pkt_start[c] + atomicAdd(&plan->cursor[c], 1u)] = i;
+    const uint32_t k = keys[i];
+    perm[plan->pkt_start[k] + atomicAdd(&plan->cursor[k], 1u)] = i;
 }
 
 __global__ void __launch_bounds__(kWave)
@@ -150,14 +177,15 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
 
     const uint32_t b = blockIdx.x;
     if (b >= plan->total_waves) return;
-    uint32_t cls = 0;
-#pragma unroll
-    for (int c = 0; c < alac::NUM_CLASSES; ++c)
-        if (b >= plan->wave_start[c] && b < plan->wave_start[c] + (plan->count[c] + ppw - 1) / ppw) cls = (uint32_t)c;
+    /* which key owns block b: last list entry whose first wave is <= b (a handful of entries) */
+    uint32_t e = 0;
+    for (uint32_t t = 1; t < plan->nk; ++t)
+        if (plan->list_wave0[t] <= b) e = t;
+    const uint32_t key = plan->list_key[e];
     const uint32_t lane = threadIdx.x;
-    const uint32_t idx = (b - plan->wave_start[cls]) * ppw + lane;
-    const bool live = lane < ppw && idx < plan->count[cls];
-    const uint32_t pkt = live ? perm[plan->pkt_start[cls] + idx] : 0u;
+    const uint32_t idx = (b - plan->list_wave0[e]) * ppw + lane;
+    const bool live = lane < ppw && idx < plan->count[key];
+    const uint32_t pkt = live ? perm[plan->pkt_start[key] + idx] : 0u;
 
     GpuWave wv;
     wv.rows = s_rows;
@@ -169,17 +197,22 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     wv.lane = lane;
     wv.wcnt = wv.flushed = 0;
 
-    const uint8_t* p = blob + (live ? offsets[pkt] : 0ull);
+    const uint8_t* p = blob + (live ? offsets[pkt] : offsets[0]);
     const uint32_t size = live ? sizes[pkt] : 0u;
     uint8_t* o = out + (size_t)pkt * out_stride;
     uint32_t frames = 0;
     int32_t st;
-    /* cls is wave-uniform (one class per block): a scalar branch picks the variant */
-    switch (__builtin_amdgcn_readfirstlane(cls)) {
-        case alac::CLASS_NA4: st = alac::decode_wave<GpuWave, 4, false>(wv, cfg, live, p, size, o, &frames); break;
-        case alac::CLASS_NA6: st = alac::decode_wave<GpuWave, 6, false>(wv, cfg, live, p, size, o, &frames); break;
-        case alac::CLASS_NA8: st = alac::decode_wave<GpuWave, 8, false>(wv, cfg, live, p, size, o, &frames); break;
-        default: st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, o, &frames); break;
+    /* the key is wave-uniform (one key per block): scalar branches pick the variant */
+    const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+    if (ukey < 1024u) {
+        st = alac::decode_regular<GpuWave>(wv, cfg, ukey, live, p, size, o, &frames);
+    } else {
+        switch (ukey - 1024u) {
+            case alac::CLASS_NA4: st = alac::decode_wave<GpuWave, 4, false>(wv, cfg, live, p, size, o, &frames); break;
+            case alac::CLASS_NA6: st = alac::decode_wave<GpuWave, 6, false>(wv, cfg, live, p, size, o, &frames); break;
+            case alac::CLASS_NA8: st = alac::decode_wave<GpuWave, 8, false>(wv, cfg, live, p, size, o, &frames); break;
+            default: st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, o, &frames); break;
+        }
     }
     if (live) {
         frames_out[pkt] = frames;
@@ -272,7 +305,8 @@ struct alacgpu_decoder {
 
 namespace {
 
-size_t max_waves(size_t n, uint32_t ppw) { return (n + ppw - 1) / ppw + alac::NUM_CLASSES; }
+/* upper bound on the waves of a batch: every key present may end in one partly filled wave */
+size_t max_waves(size_t n, uint32_t ppw) { return (n + ppw - 1) / ppw + std::min<size_t>(n, 48); }
 
 /* Packets per wave. The lock-step loop is a dependent chain that one wave issues at ~1 instruction per 4-5
  * cycles, so the machine is filled by MORE WAVES, not fuller ones: below ~2 resident waves per SIMD a batch is
@@ -293,7 +327,7 @@ int reserve_workspace(alacgpu_decoder* dec, size_t n, uint32_t ppw) {
     if ((rc = dec->scratch_u.ensure(waves * dec->cfg.frame_length * ppw * sizeof(int32_t)))) return rc;
     if ((rc = dec->scratch_g.ensure(waves * kFallbackSlots * ppw * sizeof(int32_t)))) return rc;
     if ((rc = dec->plan.ensure(sizeof(Plan)))) return rc;
-    if ((rc = dec->cls.ensure(n ? n : 1))) return rc;
+    if ((rc = dec->cls.ensure((n ? n : 1) * sizeof(uint16_t)))) return rc;
     if ((rc = dec->perm.ensure((n ? n : 1) * sizeof(uint32_t)))) return rc;
     return ALACGPU_E_OK;
 }
@@ -313,10 +347,10 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
     Plan* plan = (Plan*)dec->plan.p;
     const uint32_t nb = (uint32_t)((n + 255) / 256);
     HIP_TRY(hipMemsetAsync(plan, 0, sizeof(Plan), dec->stream));
-    hipLaunchKernelGGL(alac_classify, dim3(nb), dim3(256), 0, dec->stream, d_blob, d_offsets, d_sizes, (uint32_t)n,
-                       (uint8_t*)dec->cls.p, plan);
+    hipLaunchKernelGGL(alac_classify, dim3(nb), dim3(256), 0, dec->stream, c, d_blob, d_offsets, d_sizes, (uint32_t)n,
+                       (uint16_t*)dec->cls.p, plan);
     hipLaunchKernelGGL(alac_plan, dim3(1), dim3(1), 0, dec->stream, plan, ppw);
-    hipLaunchKernelGGL(alac_scatter, dim3(nb), dim3(256), 0, dec->stream, (const uint8_t*)dec->cls.p, (uint32_t)n, plan,
+    hipLaunchKernelGGL(alac_scatter, dim3(nb), dim3(256), 0, dec->stream, (const uint16_t*)dec->cls.p, (uint32_t)n, plan,
                        (uint32_t*)dec->perm.p);
     const uint32_t slot = (uint32_t)(dec->launches % kTimingSlots);
     HIP_TRY(hipEventRecord(dec->ev_start[slot], dec->stream));

@@ -13,6 +13,7 @@
 
 #define ALAC_DEV inline
 #include "../../saprobe-alac_amd/csrc/alac_wave.h"
+#include "../../saprobe-alac_amd/csrc/alac_regular.h"
 
 namespace {
 
@@ -32,6 +33,10 @@ struct HostWave {
         memcpy(st_out + 4u * (size_t)st_cnt, &v, 4);
         ++st_cnt;
     }
+    void st_push_if(uint32_t v, bool on) {
+        if (on) st_push(v);
+    }
+    void st_tail16(uint16_t h) { memcpy(st_out + 4u * (size_t)st_cnt, &h, 2); }
     void st_step() {}
     uint32_t st_finish() { return st_cnt; }
     int32_t* u_row(uint32_t i) { return &u_tile[i]; }
@@ -40,8 +45,9 @@ struct HostWave {
 
 }  // namespace
 
-/* variant: 0..3 = force that class's kernel variant (any class must decode any packet correctly);
- *          -1   = pick by classify_packet like the GPU pre-pass does. classes_out (may be null) gets the class. */
+/* variant: 0..3 = force that class's generic variant (any class must decode any packet correctly);
+ *          -1   = pick like the GPU pre-pass does (lean decoder for regular packets). classes_out (may be null)
+ *                 gets the sort key. */
 extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* blob, const uint64_t* offsets,
                                      const uint32_t* sizes, size_t n, uint8_t* out, size_t out_stride,
                                      uint32_t* frames_out, int32_t* status, int poison, int variant,
@@ -65,9 +71,18 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
         }
         const uint8_t* p = blob + offsets[i];
         uint8_t* o = out + i * out_stride;
-        const uint32_t cls = variant >= 0 ? (uint32_t)variant : alac::classify_packet(p, sizes[i]);
-        if (classes_out) classes_out[i] = cls;
         frames_out[i] = 0;
+        if (variant < 0) {
+            /* like the GPU pre-pass: regular packets take the lean decoder */
+            const uint32_t key = alac::classify_regular(dc, p, sizes[i]);
+            if (key != alac::KEY_IRREGULAR) {
+                if (classes_out) classes_out[i] = key;
+                status[i] = alac::decode_regular<HostWave>(wv, dc, key, true, p, sizes[i], o, &frames_out[i]);
+                continue;
+            }
+        }
+        const uint32_t cls = variant >= 0 ? (uint32_t)variant : alac::classify_packet(p, sizes[i]);
+        if (classes_out) classes_out[i] = 1024u + cls;
         switch (cls) {
             case alac::CLASS_NA4: status[i] = alac::decode_wave<HostWave, 4, false>(wv, dc, true, p, sizes[i], o, &frames_out[i]); break;
             case alac::CLASS_NA6: status[i] = alac::decode_wave<HostWave, 6, false>(wv, dc, true, p, sizes[i], o, &frames_out[i]); break;
