@@ -64,6 +64,7 @@ struct GpuWave {
     uint8_t* my_out;
     uint32_t lane, wcnt, flushed;
     uint32_t ppw;              /* packets (= live lanes) per wave; also the row stride of the HBM tiles */
+    uint32_t u_stride;         /* ppw, or 0 for lanes >= ppw: they own one dummy cell behind the tile */
 
     ALAC_DEV bool any(bool p) const { return __ballot(p) != 0ull; }
     ALAC_DEV uint32_t max_u32(uint32_t v) const {
@@ -121,7 +122,7 @@ struct GpuWave {
         flushed = wcnt;
         return wcnt;
     }
-    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * ppw; }
+    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * u_stride; }
     ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * ppw; }
 };
 
@@ -190,7 +191,11 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     GpuWave wv;
     wv.rows = s_rows;
     wv.optr = s_optr;
-    wv.u_tile = scratch_u + (size_t)b * cfg.frame_length * ppw + lane;
+    /* U tile: frame_length rows of ppw cells, then 64 dummy cells for the lanes that hold no packet (the lean
+     * decoder stores without a branch, so every lane needs a cell of its own) */
+    const size_t tile_cells = (size_t)cfg.frame_length * ppw + kWave;
+    wv.u_stride = lane < ppw ? ppw : 0u;
+    wv.u_tile = scratch_u + (size_t)b * tile_cells + (lane < ppw ? lane : (size_t)cfg.frame_length * ppw + lane);
     wv.g_tile = scratch_g + (size_t)b * kFallbackSlots * ppw + lane;
     wv.ppw = ppw;
     wv.my_out = nullptr;
@@ -324,7 +329,7 @@ uint32_t pick_ppw(size_t n) {
 int reserve_workspace(alacgpu_decoder* dec, size_t n, uint32_t ppw) {
     const size_t waves = max_waves(n, ppw);
     int rc;
-    if ((rc = dec->scratch_u.ensure(waves * dec->cfg.frame_length * ppw * sizeof(int32_t)))) return rc;
+    if ((rc = dec->scratch_u.ensure(waves * ((size_t)dec->cfg.frame_length * ppw + kWave) * sizeof(int32_t)))) return rc;
     if ((rc = dec->scratch_g.ensure(waves * kFallbackSlots * ppw * sizeof(int32_t)))) return rc;
     if ((rc = dec->plan.ensure(sizeof(Plan)))) return rc;
     if ((rc = dec->cls.ensure((n ? n : 1) * sizeof(uint16_t)))) return rc;
