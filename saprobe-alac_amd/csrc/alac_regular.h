@@ -26,8 +26,9 @@
 /* |a - b| + c on unsigned operands: v_sad_u32 on the GPU */
 #define ALAC_SAD(a, b, c) (((a) > (b) ? (a) - (b) : (b) - (a)) + (c))
 #endif
-#ifndef ALAC_MED3
-#define ALAC_MED3(x, lo, hi) ((x) < (lo) ? (lo) : (x) > (hi) ? (hi) : (x))
+#ifndef ALAC_SIGN
+/* -1 / 0 / +1: one v_med3_i32 on the GPU */
+#define ALAC_SIGN(x) (((x) > 0) - ((x) < 0))
 #endif
 
 namespace alac {
@@ -185,11 +186,17 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane&
 #pragma unroll
     for (int j = 0; j <= NA; ++j) hb[j] = BIAS;
     uint32_t held = 0; /* mono: low half of the dword under construction */
+    int32_t u_next = 0;
+    if (LAST && CPE) u_next = *wv.u_row(0);
 
     for (uint32_t i = 0; i < n_it; ++i) {
         const bool on = i < ns && s.err == 0;
         int32_t u_pre = 0;
-        if (LAST && CPE) u_pre = *wv.u_row(i); /* issued first: its latency hides behind the decode */
+        if (LAST && CPE) {
+            /* U hand-off, fetched one step ahead (row n_it <= frame_length exists: the tile ends in spare cells) */
+            u_pre = u_next;
+            u_next = *wv.u_row(i + 1u);
+        }
 
         /* ---- one residual (DynDecomp, golomb.go:167-247), common path without branches ---------------------- */
         const bool inrun = s.zrem != 0;
@@ -231,19 +238,23 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane&
             const bool neg = del < 0;
             const uint32_t big_d0 = (uint32_t)(neg ? -del : del);
             const uint32_t rnd = neg ? rnd_neg : 0u;
-            const int32_t msdir = neg ? 1 : -1;
-            int32_t acc = den_half;
+            /* delta_j = sign(del) * -sign(d_j) as (sd ^ nmask) + pm: identity for del < 0, negation otherwise */
+            const uint32_t nmask = neg ? 0u : 0xffffffffu;
+            const uint32_t pm = neg ? 0u : 1u;
+            int32_t dot = 0;
             uint32_t run = 0;
 #pragma unroll
             for (int j = NA - 1; j >= 0; --j) {
                 const int32_t d = (int32_t)(topb - hb[j]); /* top - out[i-1-j]; the bias cancels */
-                acc -= ALAC_MUL24(coef[j], d);
-                const int32_t sd = ALAC_MED3(d, -1, 1);
+                dot += ALAC_MUL24(coef[j], d);             /* uses coef[j] before its update */
+                const int32_t sd = ALAC_SIGN(d);
+                const int32_t delta = (int32_t)(((uint32_t)sd ^ nmask) + pm);
                 const uint32_t q = ALAC_SAD(topb, hb[j], rnd) >> den_shift;
-                const bool act = run < big_d0;
-                coef[j] = act ? coef[j] + ALAC_MUL24(sd, msdir) : coef[j];
+                const int32_t step = run < big_d0 ? delta : 0; /* a select of two ready values: no branch */
+                coef[j] += step;
                 run += (uint32_t)ALAC_MUL24((int32_t)q, NA - j);
             }
+            const int32_t acc = den_half - dot;
             o = sext_cs(del + (int32_t)(topb ^ BIAS) + (acc >> den_shift), chan_shift);
         }
 #pragma unroll

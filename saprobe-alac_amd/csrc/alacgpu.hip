@@ -26,9 +26,14 @@
 #define ALAC_DEV __device__ __forceinline__
 #define ALAC_NOINLINE
 #define ALAC_MUL24(a, b) __mul24((int)(a), (int)(b))
-/* written so that instruction selection picks v_sad_u32 and v_med3_i32 */
+/* written so that instruction selection picks v_sad_u32 */
 #define ALAC_SAD(a, b, c) ((max((uint32_t)(a), (uint32_t)(b)) - min((uint32_t)(a), (uint32_t)(b))) + (uint32_t)(c))
-#define ALAC_MED3(x, lo, hi) min(max((int32_t)(x), (int32_t)(lo)), (int32_t)(hi))
+__device__ __forceinline__ int32_t alac_sign_med3(int32_t x) {
+    int32_t r;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(x));
+    return r;
+}
+#define ALAC_SIGN(x) alac_sign_med3(x)
 #include "alac_wave.h"
 #include "alac_regular.h"
 

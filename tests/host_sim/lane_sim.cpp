@@ -22,7 +22,7 @@ struct HostWave {
     std::vector<int32_t> u_tile, g_tile;
     uint8_t* st_out = nullptr;
     uint32_t st_cnt = 0;
-    explicit HostWave(uint32_t frame_length) : u_tile(frame_length ? frame_length : 1), g_tile(64) {}
+    explicit HostWave(uint32_t frame_length) : u_tile((frame_length ? frame_length : 1) + 1), g_tile(64) {}
     bool any(bool p) const { return p; }
     uint32_t max_u32(uint32_t v) const { return v; }
     void st_begin(uint8_t* out) {
