@@ -104,9 +104,9 @@ typedef enum alacgpu_stage {
 
 /* Every packet in a device-resident blob must be followed by at least this many
  * zero bytes (the reference pads each packet with 4, bitbuffer.go:33; the kernel's
- * bitstream cache prefetches two dwords further). Packet starts need no alignment
+ * bitstream ring is refilled in 16-byte blocks ahead of the read position). Packet starts need no alignment
  * (16 bytes is what alacgpu_decode_batch produces when it re-packs host input). */
-#define ALACGPU_PACKET_PAD 32
+#define ALACGPU_PACKET_PAD 64
 
 typedef struct alacgpu_decoder alacgpu_decoder;
 

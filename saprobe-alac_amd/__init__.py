@@ -34,7 +34,7 @@ __all__ = [
     "ErrConfig", "ErrDecode", "AlacError", "build", "lib", "lib_path",
 ]
 
-PACKET_PAD = 32  # ALACGPU_PACKET_PAD
+PACKET_PAD = 64  # ALACGPU_PACKET_PAD
 
 
 # ---- errors: errors.go:22-34 and internal/alac/errors.go:24-33 -------------------------------------

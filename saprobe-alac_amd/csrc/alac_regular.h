@@ -76,29 +76,113 @@ ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32
     return nu * 32u + nv;
 }
 
-/* FastRd::slide without a branch: the cache moves by 0 or 1 dword (a step consumes <= 32 bits; the slow path
- * re-seeks), and the look-ahead dword is (re)loaded every step. */
-ALAC_DEV void slide_branchless(FastRd& rd, uint32_t pos) {
-    const uint32_t ni = (pos + rd.bias) >> 5;
-    const bool cross = ni != rd.widx;
-    rd.w0 = cross ? rd.w1 : rd.w0;
-    rd.w1 = cross ? rd.w2 : rd.w1;
-    rd.widx = ni;
-    rd.w2 = FastRd::ld(rd.base + ni + 2);
-}
+/* ---- the lean path's bit reader: an LDS ring per lane, refilled ahead of time --------------------------------
+ * w0,w1 hold stream dwords widx, widx+1 and w2 the next one, as in FastRd, but they are fed from a 32-dword ring
+ * in LDS (W::ring_*), never straight from HBM. The ring is topped up 16 bytes at a time on a wave-uniform
+ * schedule (every 4th step): tick() first commits the block whose global load was issued 4 steps earlier, then
+ * issues the next one. So no step ever waits on an HBM/L2 round trip: the data a step needs left memory at
+ * least four steps ago, and each packet byte is fetched from L2 exactly once. A plain step consumes <= 32 bits,
+ * so 4 dwords per 4 steps sustain it (reseek() covers the slow path); start() prefills 16 dwords. Loads stay inside size +
+ * ALACGPU_PACKET_PAD; positions past size*8 + 66 bits are never decoded here. */
+template <class W>
+struct RingRd {
+    const uint32_t* base; /* packet start rounded down to a dword */
+    uint32_t bias;        /* stream bit 0 is bit `bias` of base[0] */
+    uint32_t limit;       /* first dword index that may not be loaded */
+    uint32_t w0, w1, w2, widx;
+    uint32_t fill;        /* ring holds dwords [fill-32, fill); multiple of 4 */
+    uint32_t p0, p1, p2, p3;
+    bool pend;
+
+    ALAC_DEV void init(const uint8_t* pkt, uint32_t size) {
+        base = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(pkt) & ~(uintptr_t)3);
+        bias = (uint32_t)(reinterpret_cast<uintptr_t>(pkt) & 3u) * 8u;
+        limit = ((bias >> 3) + size + ALACGPU_PACKET_PAD - 16u) >> 2; /* a 16-byte block starting below it stays inside the pad */
+        w0 = w1 = w2 = widx = fill = 0;
+        p0 = p1 = p2 = p3 = 0;
+        pend = false;
+    }
+    ALAC_DEV void load4(uint32_t at) {
+        const uint32_t* q = base + at;
+        p0 = __builtin_bswap32(q[0]);
+        p1 = __builtin_bswap32(q[1]);
+        p2 = __builtin_bswap32(q[2]);
+        p3 = __builtin_bswap32(q[3]);
+    }
+    /* channel start: synchronous prefill from the block holding `pos` */
+    ALAC_DEV void start(W& wv, uint32_t pos) {
+        const uint32_t ni = (pos + bias) >> 5;
+        fill = ni & ~3u;
+        pend = false;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (fill < limit) {
+                load4(fill);
+                wv.ring_write4(fill & 31u, p0, p1, p2, p3);
+                fill += 4u;
+            }
+        }
+        reseek(wv, pos);
+    }
+    ALAC_DEV void reseek(W& wv, uint32_t pos) {
+        widx = (pos + bias) >> 5;
+        /* a slow-path step (escape code + zero-run code) can eat more than one dword, more than tick() puts
+         * back: top the ring up on the spot whenever it runs low. Plain steps take <= 32 bits (prefix + 1 + k,
+         * k <= 23), which the 4 dwords per 4 steps of tick() cover. */
+        while (fill < widx + 12u && fill < limit) {
+            if (!pend) load4(fill);
+            wv.ring_write4(fill & 31u, p0, p1, p2, p3);
+            fill += 4u;
+            pend = false;
+        }
+        w0 = wv.ring_read(widx & 31u);
+        w1 = wv.ring_read((widx + 1u) & 31u);
+        w2 = wv.ring_read((widx + 2u) & 31u);
+    }
+    ALAC_DEV uint32_t window(uint32_t pos) const {
+        const uint32_t r = (pos + bias) & 31u;
+        return (uint32_t)(((((uint64_t)w0) << 32) | w1) << r >> 32);
+    }
+    /* no branch: the cache moves by 0 or 1 dword (the slow path reseeks), w2 is re-read from LDS every step */
+    ALAC_DEV void slide(W& wv, uint32_t pos) {
+        const uint32_t ni = (pos + bias) >> 5;
+        const bool cross = ni != widx;
+        w0 = cross ? w1 : w0;
+        w1 = cross ? w2 : w1;
+        widx = ni;
+        w2 = wv.ring_read((ni + 2u) & 31u);
+#ifdef ALAC_RING_DEBUG
+        if (ni + 2u < limit && w2 != __builtin_bswap32(base[ni + 2u]))
+            fprintf(stderr, "ring mismatch at dword %u (fill %u widx %u limit %u pend %d)\n", ni + 2u, fill, widx, limit, (int)pend);
+#endif
+    }
+    /* every 4th step, wave-uniform */
+    ALAC_DEV void tick(W& wv) {
+        if (pend) {
+            wv.ring_write4(fill & 31u, p0, p1, p2, p3);
+            fill += 4u;
+            pend = false;
+        }
+        if (fill + 4u <= widx + 32u && fill < limit) {
+            load4(fill);
+            pend = true;
+        }
+    }
+};
 
 /* per-lane Golomb + reader state of one channel */
+template <class W>
 struct RegLane {
-    FastRd rd;
+    RingRd<W> rd;
     uint32_t pos, mean, zmode, zrem, pb, max_pos;
     int32_t err;
 };
 
 /* The rare part of DynDecomp (golomb.go:167-247) for one lane: overrun, an escape code, and/or the start of a
  * zero run. Redoes the sample from its start with the stateless reader; returns the residual. */
-template <class BitsT>
-ALAC_DEV ALAC_NOINLINE int32_t golomb_slow(const BitsT& bits, RegLane& s, uint32_t size, uint32_t kb, uint32_t wb,
-                                           uint32_t chan_bits, uint32_t i, uint32_t ns) {
+template <class W>
+ALAC_DEV ALAC_NOINLINE int32_t golomb_slow(W& wv, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t kb,
+                                           uint32_t wb, uint32_t chan_bits, uint32_t i, uint32_t ns) {
     if (s.pos >= s.max_pos) {
         s.err = ST_OVERRUN; /* golomb.go:168-170 */
         return 0;
@@ -160,7 +244,7 @@ ALAC_DEV ALAC_NOINLINE int32_t golomb_slow(const BitsT& bits, RegLane& s, uint32
         if (rl >= 65535u) s.zmode = 0;
         s.mean = 0;
     }
-    s.rd.seek(s.pos);
+    s.rd.reseek(wv, s.pos);
     return del;
 }
 
@@ -169,7 +253,7 @@ ALAC_DEV ALAC_NOINLINE int32_t golomb_slow(const BitsT& bits, RegLane& s, uint32
  * LAST: this channel completes the frame (V of a pair, or the mono channel): unmix and emit PCM.
  */
 template <class W, int NA, bool LAST, bool CPE>
-ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane& s, uint32_t size, uint32_t ns,
+ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
                             uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
                             uint32_t mix_sh) {
     constexpr uint32_t BIAS = 0x80000000u;
@@ -191,6 +275,7 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane&
 
     for (uint32_t i = 0; i < n_it; ++i) {
         const bool on = i < ns && s.err == 0;
+        if ((i & 3u) == 0) s.rd.tick(wv); /* scalar test: bitstream ring refill, 4 steps ahead of need */
         int32_t u_pre = 0;
         if (LAST && CPE) {
             /* U hand-off, fetched one step ahead (row n_it <= frame_length exists: the tile ends in spare cells) */
@@ -217,14 +302,14 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane&
         int32_t del = (nd & 1u) ? -half : half;
         if (inrun) del = 0;
         if (wv.any(slow)) {
-            if (slow) del = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns);
+            if (slow) del = golomb_slow(wv, bits, s, size, kb, wb, chan_bits, i, ns);
         }
         const bool commit = dec && !slow;
         s.pos = commit ? s.pos + pre + k + (big ? 1u : 0u) : s.pos; /* prefix + 1, then k bits (v >= 2) or k - 1 */
         s.mean = commit ? mean2 : s.mean;
         s.zmode = commit ? 0u : s.zmode;
         s.zrem = (on && inrun) ? s.zrem - 1u : s.zrem;
-        slide_branchless(s.rd, s.pos);
+        s.rd.slide(wv, s.pos);
 
         /* ---- one predictor step (UnpcBlock, predictor.go:45-94) ------------------------------------------------ */
         int32_t o;
@@ -290,7 +375,7 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane&
 
 /* the order switch is scalar: NA is wave-uniform by construction of the waves */
 template <class W, bool LAST, bool CPE>
-ALAC_DEV void regular_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bits, RegLane& s, uint32_t size,
+ALAC_DEV void regular_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size,
                                uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
                                int32_t mix_res, uint32_t mix_sh) {
     switch (na) {
@@ -312,10 +397,8 @@ ALAC_DEV int32_t decode_regular(W& wv, const DevCfg& cfg, uint32_t key, bool liv
     const bool cpe = cfg.num_channels == 2;
     const uint32_t na_u = key >> 5, na_v = key & 31u;
 
-    RegLane s;
-    s.rd.base = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(pkt) & ~(uintptr_t)3);
-    s.rd.bias = (uint32_t)(reinterpret_cast<uintptr_t>(pkt) & 3u) * 8u;
-    s.rd.w0 = s.rd.w1 = s.rd.w2 = s.rd.widx = 0;
+    RegLane<W> s;
+    s.rd.init(pkt, size);
     s.err = 0;
     s.max_pos = size * 8u;
 
@@ -346,7 +429,7 @@ ALAC_DEV int32_t decode_regular(W& wv, const DevCfg& cfg, uint32_t key, bool liv
     s.zmode = 0;
     s.zrem = 0;
     s.pb = (cfg.pb * ((hu >> 5) & 7u)) / 4u; /* decoder.go:299 */
-    if (live) s.rd.seek(s.pos);
+    s.rd.start(wv, live ? s.pos : 0u);
     if (cpe) regular_phase_na<W, false, true>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh);
     else regular_phase_na<W, true, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0);
     uint32_t err_chan = 0;
@@ -359,7 +442,7 @@ ALAC_DEV int32_t decode_regular(W& wv, const DevCfg& cfg, uint32_t key, bool liv
         s.zmode = 0;
         s.zrem = 0;
         s.pb = (cfg.pb * ((hv >> 5) & 7u)) / 4u;
-        if (live && s.err == 0) s.rd.seek(s.pos);
+        s.rd.start(wv, (live && s.err == 0) ? s.pos : 0u);
         regular_phase_na<W, true, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh);
         if (err_u == 0 && s.err != 0) err_chan = 1;
     }

@@ -44,6 +44,7 @@ constexpr uint32_t kTimingSlots = 64;
 constexpr uint32_t kRowStride = 65; /* dwords per lane row in LDS: odd stride = conflict-free column access */
 constexpr uint32_t kRing = 64;      /* dwords of PCM a lane row holds (two 128-B chunks) */
 constexpr uint32_t kFallbackSlots = 64;
+constexpr uint32_t kRingStride = 36; /* 32 ring dwords + 4: rows stay 16-byte aligned, lanes spread over banks */
 
 /* device-side launch plan, rebuilt by every decode */
 /* sort keys: 0..1023 regular packets (numU*32 + numV, alac_regular.h); 1024+c irregular packets of
@@ -63,6 +64,7 @@ struct Plan {
 /* ---- gfx950 wave policy for alac::decode_wave --------------------------------------------------------- */
 struct GpuWave {
     uint32_t* rows;            /* LDS [64][kRowStride] */
+    uint32_t* bring;           /* LDS [64][kRingStride]: bitstream rings */
     unsigned long long* optr;  /* LDS [64]: PCM slot of each lane's packet */
     int32_t* u_tile;           /* HBM: this lane's column of the wave's U hand-off tile */
     int32_t* g_tile;           /* HBM: this lane's column of the wave's fall-back tile */
@@ -127,6 +129,11 @@ struct GpuWave {
         flushed = wcnt;
         return wcnt;
     }
+    /* bitstream ring of the lean decoder: 32 dwords per lane, rows of kRingStride dwords (16-byte aligned) */
+    ALAC_DEV void ring_write4(uint32_t slot, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+        *reinterpret_cast<uint4*>(bring + lane * kRingStride + slot) = make_uint4(a, b, c, d);
+    }
+    ALAC_DEV uint32_t ring_read(uint32_t slot) const { return bring[lane * kRingStride + slot]; }
     ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * u_stride; }
     ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * ppw; }
 };
@@ -180,6 +187,7 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
             uint32_t ppw) {
     __shared__ uint32_t s_rows[kWave * kRowStride];
     __shared__ unsigned long long s_optr[kWave];
+    __shared__ __attribute__((aligned(16))) uint32_t s_ring[kWave * kRingStride];
 
     const uint32_t b = blockIdx.x;
     if (b >= plan->total_waves) return;
@@ -196,6 +204,7 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     GpuWave wv;
     wv.rows = s_rows;
     wv.optr = s_optr;
+    wv.bring = s_ring;
     /* U tile: frame_length rows of ppw cells, then 64 dummy cells for the lanes that hold no packet (the lean
      * decoder stores without a branch, so every lane needs a cell of its own) */
     const size_t tile_cells = (size_t)cfg.frame_length * ppw + kWave;

@@ -15,7 +15,7 @@ _LIB = None
 PROFILE_MUSIC, PROFILE_NOISE, PROFILE_QUIET, PROFILE_STRESS, PROFILE_MUSIC_LE8 = 0, 1, 2, 3, 4
 COEF_WARM, COEF_RANDOM, COEF_GIVEN = 0, 1, 2
 FLAG_LEADING_FIL, FLAG_MID_DSE, FLAG_NO_END = 1, 2, 4
-PACKET_PAD = 32
+PACKET_PAD = 64
 BASE_SEED = 0x5A9B0BE
 
 

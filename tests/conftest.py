@@ -75,7 +75,7 @@ def lane_sim(oracle):
     return run
 
 
-def pack_packets(packets, pad=32):
+def pack_packets(packets, pad=64):
     """List of packet bytes -> (blob, offsets[n], sizes[n]) in the device blob layout."""
     offs, sizes, buf = [], [], bytearray()
     for q in packets:

@@ -39,6 +39,14 @@ struct HostWave {
     void st_tail16(uint16_t h) { memcpy(st_out + 4u * (size_t)st_cnt, &h, 2); }
     void st_step() {}
     uint32_t st_finish() { return st_cnt; }
+    uint32_t ring[32] = {0};
+    void ring_write4(uint32_t slot, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+        ring[slot] = a;
+        ring[slot + 1] = b;
+        ring[slot + 2] = c;
+        ring[slot + 3] = d;
+    }
+    uint32_t ring_read(uint32_t slot) const { return ring[slot]; }
     int32_t* u_row(uint32_t i) { return &u_tile[i]; }
     int32_t* g_slot(uint32_t k) { return &g_tile[k]; }
 };
