@@ -95,19 +95,24 @@ struct RingRd {
     bool pend;
 
     ALAC_DEV void init(const uint8_t* pkt, uint32_t size) {
-        base = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(pkt) & ~(uintptr_t)3);
-        bias = (uint32_t)(reinterpret_cast<uintptr_t>(pkt) & 3u) * 8u;
+        /* pointer arithmetic, not an integer round trip: the compiler keeps the global address space */
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(pkt) & 3u);
+        base = reinterpret_cast<const uint32_t*>(pkt - mis);
+        bias = mis * 8u;
         limit = ((bias >> 3) + size + ALACGPU_PACKET_PAD - 16u) >> 2; /* a 16-byte block starting below it stays inside the pad */
         w0 = w1 = w2 = widx = fill = 0;
         p0 = p1 = p2 = p3 = 0;
         pend = false;
     }
     ALAC_DEV void load4(uint32_t at) {
-        const uint32_t* q = base + at;
-        p0 = __builtin_bswap32(q[0]);
-        p1 = __builtin_bswap32(q[1]);
-        p2 = __builtin_bswap32(q[2]);
-        p3 = __builtin_bswap32(q[3]);
+        struct __attribute__((packed, aligned(4))) Quad {
+            uint32_t a, b, c, d;
+        };
+        const Quad q = *reinterpret_cast<const Quad*>(base + at); /* one 16-byte load, 4-byte aligned */
+        p0 = __builtin_bswap32(q.a);
+        p1 = __builtin_bswap32(q.b);
+        p2 = __builtin_bswap32(q.c);
+        p3 = __builtin_bswap32(q.d);
     }
     /* channel start: synchronous prefill from the block holding `pos` */
     ALAC_DEV void start(W& wv, uint32_t pos) {

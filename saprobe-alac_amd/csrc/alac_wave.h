@@ -209,8 +209,12 @@ ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t*
     const uint32_t wb = go_shl(1u, cfg.kb) - 1u; /* SetAGParams golomb.go:60 */
 
     FastRd rd;
-    rd.base = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(pkt) & ~(uintptr_t)3);
-    rd.bias = (uint32_t)(reinterpret_cast<uintptr_t>(pkt) & 3u) * 8u;
+    {
+        /* pointer arithmetic, not an integer round trip: the compiler keeps the global address space */
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(pkt) & 3u);
+        rd.base = reinterpret_cast<const uint32_t*>(pkt - mis);
+        rd.bias = mis * 8u;
+    }
     rd.w0 = rd.w1 = rd.w2 = rd.widx = 0;
 
     uint32_t pos = 0;

@@ -39,6 +39,8 @@ __device__ __forceinline__ int32_t alac_sign_med3(int32_t x) {
 
 namespace {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 constexpr uint32_t kWave = 64;
 constexpr uint32_t kTimingSlots = 64;
 constexpr uint32_t kRowStride = 65; /* dwords per lane row in LDS: odd stride = conflict-free column access */
@@ -61,11 +63,14 @@ struct Plan {
     uint32_t total_waves;
 };
 
+/* LDS of the decode kernel (one wave per workgroup). Referenced by name, never through a generic pointer, so
+ * every access is a ds_* instruction (a pointer kept in a struct decays to flat_* loads and stores). */
+__shared__ uint32_t s_rows[kWave * kRowStride];                                  /* PCM stager rows */
+__shared__ unsigned long long s_optr[kWave];                                     /* PCM slot of each lane's packet */
+__shared__ __attribute__((aligned(16))) uint32_t s_ring[kWave * kRingStride];    /* bitstream rings */
+
 /* ---- gfx950 wave policy for alac::decode_wave --------------------------------------------------------- */
 struct GpuWave {
-    uint32_t* rows;            /* LDS [64][kRowStride] */
-    uint32_t* bring;           /* LDS [64][kRingStride]: bitstream rings */
-    unsigned long long* optr;  /* LDS [64]: PCM slot of each lane's packet */
     int32_t* u_tile;           /* HBM: this lane's column of the wave's U hand-off tile */
     int32_t* g_tile;           /* HBM: this lane's column of the wave's fall-back tile */
     uint8_t* my_out;
@@ -84,16 +89,16 @@ struct GpuWave {
     }
     ALAC_DEV void st_begin(uint8_t* out) {
         my_out = out;
-        optr[lane] = (unsigned long long)reinterpret_cast<uintptr_t>(out);
+        s_optr[lane] = (unsigned long long)reinterpret_cast<uintptr_t>(out);
         wcnt = flushed = 0;
     }
     ALAC_DEV void st_push(uint32_t v) {
-        rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
+        s_rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
         ++wcnt;
     }
     /* branch-free form: a lane that is not `on` rewrites its next free slot and does not advance */
     ALAC_DEV void st_push_if(uint32_t v, bool on) {
-        rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
+        s_rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
         wcnt += on ? 1u : 0u;
     }
     /* 16-bit tail after the last whole dword (mono, odd frame count) */
@@ -114,10 +119,11 @@ struct GpuWave {
         for (uint32_t k = 0; k < groups; ++k) {
             const uint32_t q = 8u * k + (lane >> 3);
             if ((mask >> q) & 1ull) {
-                const uint32_t* r = rows + q * kRowStride + col0 + piece * 4u;
+                const uint32_t* r = s_rows + q * kRowStride + col0 + piece * 4u;
                 const uint4 v = make_uint4(r[0], r[1], r[2], r[3]);
-                uint8_t* dst = reinterpret_cast<uint8_t*>((uintptr_t)optr[q]) + ((size_t)fl + piece * 4u) * 4u;
-                *reinterpret_cast<uint4*>(dst) = v;
+                uint8_t* dst = reinterpret_cast<uint8_t*>((uintptr_t)s_optr[q]) + ((size_t)fl + piece * 4u) * 4u;
+                /* the address came through LDS as an integer: name the global address space, or it is a flat store */
+                *reinterpret_cast<__attribute__((address_space(1))) u32x4*>((uintptr_t)dst) = u32x4{v.x, v.y, v.z, v.w};
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -125,15 +131,16 @@ struct GpuWave {
     }
     ALAC_DEV uint32_t st_finish() {
         for (uint32_t w = flushed; w < wcnt; ++w)
-            *reinterpret_cast<uint32_t*>(my_out + (size_t)w * 4u) = rows[lane * kRowStride + (w & (kRing - 1u))];
+            *reinterpret_cast<uint32_t*>(my_out + (size_t)w * 4u) = s_rows[lane * kRowStride + (w & (kRing - 1u))];
         flushed = wcnt;
         return wcnt;
     }
     /* bitstream ring of the lean decoder: 32 dwords per lane, rows of kRingStride dwords (16-byte aligned) */
     ALAC_DEV void ring_write4(uint32_t slot, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-        *reinterpret_cast<uint4*>(bring + lane * kRingStride + slot) = make_uint4(a, b, c, d);
+        /* (slot >> 2) * 4 lets the compiler see the 16-byte alignment: one ds_write_b128 */
+        *reinterpret_cast<uint4*>(&s_ring[lane * kRingStride + (slot >> 2) * 4u]) = make_uint4(a, b, c, d);
     }
-    ALAC_DEV uint32_t ring_read(uint32_t slot) const { return bring[lane * kRingStride + slot]; }
+    ALAC_DEV uint32_t ring_read(uint32_t slot) const { return s_ring[lane * kRingStride + slot]; }
     ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * u_stride; }
     ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * ppw; }
 };
@@ -185,9 +192,6 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
             uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
             int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g,
             uint32_t ppw) {
-    __shared__ uint32_t s_rows[kWave * kRowStride];
-    __shared__ unsigned long long s_optr[kWave];
-    __shared__ __attribute__((aligned(16))) uint32_t s_ring[kWave * kRingStride];
 
     const uint32_t b = blockIdx.x;
     if (b >= plan->total_waves) return;
@@ -202,9 +206,6 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     const uint32_t pkt = live ? perm[plan->pkt_start[key] + idx] : 0u;
 
     GpuWave wv;
-    wv.rows = s_rows;
-    wv.optr = s_optr;
-    wv.bring = s_ring;
     /* U tile: frame_length rows of ppw cells, then 64 dummy cells for the lanes that hold no packet (the lean
      * decoder stores without a branch, so every lane needs a cell of its own) */
     const size_t tile_cells = (size_t)cfg.frame_length * ppw + kWave;
