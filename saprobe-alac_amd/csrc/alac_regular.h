@@ -26,6 +26,16 @@
 /* |a - b| + c on unsigned operands: v_sad_u32 on the GPU */
 #define ALAC_SAD(a, b, c) (((a) > (b) ? (a) - (b) : (b) - (a)) + (c))
 #endif
+#ifndef ALAC_LOAD4
+/* four consecutive dwords from a 4-byte aligned address: one global_load_dwordx4 on the GPU */
+#define ALAC_LOAD4(q, a, b, c, d) \
+    do {                         \
+        (a) = (q)[0];            \
+        (b) = (q)[1];            \
+        (c) = (q)[2];            \
+        (d) = (q)[3];            \
+    } while (0)
+#endif
 #ifndef ALAC_SIGN
 /* -1 / 0 / +1: one v_med3_i32 on the GPU */
 #define ALAC_SIGN(x) (((x) > 0) - ((x) < 0))
@@ -105,14 +115,12 @@ struct RingRd {
         pend = false;
     }
     ALAC_DEV void load4(uint32_t at) {
-        struct __attribute__((packed, aligned(4))) Quad {
-            uint32_t a, b, c, d;
-        };
-        const Quad q = *reinterpret_cast<const Quad*>(base + at); /* one 16-byte load, 4-byte aligned */
-        p0 = __builtin_bswap32(q.a);
-        p1 = __builtin_bswap32(q.b);
-        p2 = __builtin_bswap32(q.c);
-        p3 = __builtin_bswap32(q.d);
+        uint32_t qa, qb, qc, qd;
+        ALAC_LOAD4(base + at, qa, qb, qc, qd); /* one 16-byte load, 4-byte aligned */
+        p0 = __builtin_bswap32(qa);
+        p1 = __builtin_bswap32(qb);
+        p2 = __builtin_bswap32(qc);
+        p3 = __builtin_bswap32(qd);
     }
     /* channel start: synchronous prefill from the block holding `pos` */
     ALAC_DEV void start(W& wv, uint32_t pos) {
@@ -184,72 +192,75 @@ struct RegLane {
 };
 
 /* The rare part of DynDecomp (golomb.go:167-247) for one lane: overrun, an escape code, and/or the start of a
- * zero run. Redoes the sample from its start with the stateless reader; returns the residual. */
+ * zero run. Redoes the sample from its start with the stateless reader; returns the residual. Works on local
+ * copies and writes the lane state back once (stores into the state from several exits make the compiler keep
+ * it in scratch memory). */
 template <class W>
-ALAC_DEV ALAC_NOINLINE int32_t golomb_slow(W& wv, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t kb,
-                                           uint32_t wb, uint32_t chan_bits, uint32_t i, uint32_t ns) {
-    if (s.pos >= s.max_pos) {
-        s.err = ST_OVERRUN; /* golomb.go:168-170 */
-        return 0;
-    }
-    uint32_t m = s.mean >> 9;
-    const uint32_t k = umin(31u - clz32(m + 3u), kb);
-    m = (1u << k) - 1u;
-    const uint32_t w = (uint32_t)(bits.window(s.pos) >> 32);
-    uint32_t n = clz32(~w);
-    if (n >= 9) { /* getStreamBits(bitPos+9, maxSize), golomb.go:184-186,86-108 */
-        const uint32_t gpos = s.pos + 9u;
-        const uint32_t gb = gpos & 7u;
-        const bool five = chan_bits + gb > 32u;
-        if ((gpos >> 3) > size || (five && (gpos >> 3) >= size)) {
-            s.err = ST_MALFORMED;
-            return 0;
-        }
-        n = (uint32_t)(bits.window(gpos) >> (64u - chan_bits)); /* chan_bits is 16 or 17 here */
-        s.pos += 9u + chan_bits;
+ALAC_DEV int32_t golomb_slow(const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
+                             uint32_t chan_bits, uint32_t i, uint32_t ns) {
+    uint32_t pos = s.pos, mean = s.mean, zmode = s.zmode, zrem = s.zrem;
+    int32_t err = 0, del = 0;
+    if (pos >= s.max_pos) {
+        err = ST_OVERRUN; /* golomb.go:168-170 */
     } else {
-        const uint32_t v = (w << (n + 1u)) >> (32u - k);
-        s.pos += n + 1u + k - (v >= 2 ? 0u : 1u);
-        n = v >= 2 ? n * m + v - 1u : n * m;
-    }
-    const uint32_t nd = n + s.zmode;
-    const int32_t half = (int32_t)((nd + 1u) >> 1);
-    const int32_t del = (nd & 1u) ? -half : half;
-    s.mean = s.pb * nd + s.mean - ((s.pb * s.mean) >> 9);
-    if (n > 0xffffu) s.mean = 0xffffu;
-    s.zmode = 0;
-    if ((s.mean << 2) < 512u && i + 1u < ns) { /* golomb.go:223-246 */
-        s.zmode = 1;
-        int32_t k32 = (int32_t)clz32(s.mean) - 24 + (int32_t)((s.mean + 16u) >> 6);
-        if (k32 < 0) k32 = 0;
-        const uint32_t kz = (uint32_t)k32;
-        const uint32_t mz = ((1u << kz) - 1u) & wb;
-        if ((s.pos >> 3) > size) { /* dynGet's read32bit, golomb.go:115 */
-            s.err = ST_MALFORMED;
-            return del;
-        }
-        const uint32_t wz = (uint32_t)(bits.window(s.pos) >> 32);
-        const uint32_t pre = clz32(~wz);
-        uint32_t rl;
-        if (pre >= 9) {
-            rl = (wz << 9) >> 16;
-            s.pos += 25u;
+        uint32_t m = mean >> 9;
+        const uint32_t k = umin(31u - clz32(m + 3u), kb);
+        m = (1u << k) - 1u;
+        const uint32_t w = (uint32_t)(bits.window(pos) >> 32);
+        uint32_t n = clz32(~w);
+        if (n >= 9) { /* getStreamBits(bitPos+9, maxSize), golomb.go:184-186,86-108 */
+            const uint32_t gpos = pos + 9u;
+            const uint32_t gb = gpos & 7u;
+            const bool five = chan_bits + gb > 32u;
+            if ((gpos >> 3) > size || (five && (gpos >> 3) >= size)) err = ST_MALFORMED;
+            n = (uint32_t)(bits.window(gpos) >> (64u - chan_bits)); /* chan_bits is 16 or 17 here */
+            pos += 9u + chan_bits;
         } else {
-            const uint32_t val = kz == 0 ? 0u : (wz << (pre + 1u)) >> (32u - kz);
-            s.pos += pre + 1u + kz;
-            if (val < 2) {
-                rl = pre * mz;
-                s.pos -= 1u;
-            } else {
-                rl = pre * mz + val - 1u;
+            const uint32_t v = (w << (n + 1u)) >> (32u - k);
+            pos += n + 1u + k - (v >= 2 ? 0u : 1u);
+            n = v >= 2 ? n * m + v - 1u : n * m;
+        }
+        if (err == 0) {
+            const uint32_t nd = n + zmode;
+            const int32_t half = (int32_t)((nd + 1u) >> 1);
+            del = (nd & 1u) ? -half : half;
+            mean = s.pb * nd + mean - ((s.pb * mean) >> 9);
+            if (n > 0xffffu) mean = 0xffffu;
+            zmode = 0;
+            if ((mean << 2) < 512u && i + 1u < ns) { /* golomb.go:223-246 */
+                zmode = 1;
+                int32_t k32 = (int32_t)clz32(mean) - 24 + (int32_t)((mean + 16u) >> 6);
+                if (k32 < 0) k32 = 0;
+                const uint32_t kz = (uint32_t)k32;
+                const uint32_t mz = ((1u << kz) - 1u) & wb;
+                if ((pos >> 3) > size) { /* dynGet's read32bit, golomb.go:115 */
+                    err = ST_MALFORMED;
+                } else {
+                    const uint32_t wz = (uint32_t)(bits.window(pos) >> 32);
+                    const uint32_t pre = clz32(~wz);
+                    uint32_t rl;
+                    if (pre >= 9) {
+                        rl = (wz << 9) >> 16;
+                        pos += 25u;
+                    } else {
+                        const uint32_t val = kz == 0 ? 0u : (wz << (pre + 1u)) >> (32u - kz);
+                        pos += pre + kz + (val < 2 ? 0u : 1u);
+                        rl = val < 2 ? pre * mz : pre * mz + val - 1u;
+                    }
+                    if ((uint64_t)i + 1u + rl > ns) err = ST_SAMPLE_OVERRUN; /* golomb.go:232-234 */
+                    zrem = rl;
+                    if (rl >= 65535u) zmode = 0;
+                    mean = 0;
+                }
             }
         }
-        if ((uint64_t)i + 1u + rl > ns) s.err = ST_SAMPLE_OVERRUN; /* golomb.go:232-234 */
-        s.zrem = rl;
-        if (rl >= 65535u) s.zmode = 0;
-        s.mean = 0;
     }
-    s.rd.reseek(wv, s.pos);
+    const bool ok = err == 0;
+    s.pos = ok ? pos : s.pos;
+    s.mean = ok ? mean : s.mean;
+    s.zmode = ok ? zmode : s.zmode;
+    s.zrem = ok ? zrem : s.zrem;
+    s.err = err;
     return del;
 }
 
@@ -307,7 +318,10 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
         int32_t del = (nd & 1u) ? -half : half;
         if (inrun) del = 0;
         if (wv.any(slow)) {
-            if (slow) del = golomb_slow(wv, bits, s, size, kb, wb, chan_bits, i, ns);
+            if (slow) {
+                del = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns);
+                s.rd.reseek(wv, s.pos);
+            }
         }
         const bool commit = dec && !slow;
         s.pos = commit ? s.pos + pre + k + (big ? 1u : 0u) : s.pos; /* prefix + 1, then k bits (v >= 2) or k - 1 */

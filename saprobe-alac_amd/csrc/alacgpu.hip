@@ -34,6 +34,15 @@ __device__ __forceinline__ int32_t alac_sign_med3(int32_t x) {
     return r;
 }
 #define ALAC_SIGN(x) alac_sign_med3(x)
+typedef uint32_t alac_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+#define ALAC_LOAD4(q, a, b, c, d)                                                       \
+    do {                                                                                \
+        const alac_u32x4_a4 v_ = *reinterpret_cast<const alac_u32x4_a4*>(q);            \
+        (a) = v_.x;                                                                     \
+        (b) = v_.y;                                                                     \
+        (c) = v_.z;                                                                     \
+        (d) = v_.w;                                                                     \
+    } while (0)
 #include "alac_wave.h"
 #include "alac_regular.h"
 
