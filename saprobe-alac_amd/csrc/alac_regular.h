@@ -115,12 +115,15 @@ struct RingRd {
         pend = false;
     }
     ALAC_DEV void load4(uint32_t at) {
-        uint32_t qa, qb, qc, qd;
-        ALAC_LOAD4(base + at, qa, qb, qc, qd); /* one 16-byte load, 4-byte aligned */
-        p0 = __builtin_bswap32(qa);
-        p1 = __builtin_bswap32(qb);
-        p2 = __builtin_bswap32(qc);
-        p3 = __builtin_bswap32(qd);
+        /* one 16-byte load, 4-byte aligned. The dwords stay RAW (little-endian) in p0..p3: touching them here
+         * would make the wave wait for the load on the spot; commit() swaps them four steps later. */
+        ALAC_LOAD4(base + at, p0, p1, p2, p3);
+    }
+    ALAC_DEV void commit(W& wv) {
+        wv.ring_write4(fill & 31u, __builtin_bswap32(p0), __builtin_bswap32(p1), __builtin_bswap32(p2),
+                       __builtin_bswap32(p3));
+        fill += 4u;
+        pend = false;
     }
     /* channel start: synchronous prefill from the block holding `pos` */
     ALAC_DEV void start(W& wv, uint32_t pos) {
@@ -131,8 +134,7 @@ struct RingRd {
         for (int b = 0; b < 4; ++b) {
             if (fill < limit) {
                 load4(fill);
-                wv.ring_write4(fill & 31u, p0, p1, p2, p3);
-                fill += 4u;
+                commit(wv);
             }
         }
         reseek(wv, pos);
@@ -144,9 +146,7 @@ struct RingRd {
          * k <= 23), which the 4 dwords per 4 steps of tick() cover. */
         while (fill < widx + 12u && fill < limit) {
             if (!pend) load4(fill);
-            wv.ring_write4(fill & 31u, p0, p1, p2, p3);
-            fill += 4u;
-            pend = false;
+            commit(wv);
         }
         w0 = wv.ring_read(widx & 31u);
         w1 = wv.ring_read((widx + 1u) & 31u);
@@ -171,11 +171,7 @@ struct RingRd {
     }
     /* every 4th step, wave-uniform */
     ALAC_DEV void tick(W& wv) {
-        if (pend) {
-            wv.ring_write4(fill & 31u, p0, p1, p2, p3);
-            fill += 4u;
-            pend = false;
-        }
+        if (pend) commit(wv);
         if (fill + 4u <= widx + 32u && fill < limit) {
             load4(fill);
             pend = true;
