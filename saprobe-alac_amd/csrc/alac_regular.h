@@ -46,12 +46,14 @@ namespace alac {
 constexpr uint32_t KEY_IRREGULAR = 1024; /* sort key of packets for decode_wave; regular: numU*32 + numV */
 constexpr uint32_t NUM_KEYS = 1025;
 
-ALAC_DEV bool regular_order(uint32_t na) { return na == 4 || na == 5 || na == 6 || na == 8; }
+/* orders the lean decoder runs: 4/5/6/8 on exactly NA taps, the others (general form, int16 coefficient wrap) on
+ * 16 register taps with wave-uniform skips; 0 copies and 31 is delta mode. 17..30 exist only on paper. */
+ALAC_DEV bool regular_order(uint32_t na) { return na <= 16 || na == 31; }
 
 /* Sort key of a packet; no entropy decoding, reads only the element header. */
 ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32_t size) {
     if (cfg.bit_depth != 16 || cfg.num_channels > 2 || cfg.aligned16 == 0 || cfg.kb == 0 ||
-        cfg.frame_length > 65536u || cfg.frame_length <= 8u)
+        cfg.frame_length > 65536u || cfg.frame_length <= 32u)
         return KEY_IRREGULAR;
     const Bits bits{pkt, size};
     if (size < 12) return KEY_IRREGULAR;
@@ -267,7 +269,12 @@ ALAC_DEV int32_t golomb_slow(const Bits& bits, RegLane<W>& s, uint32_t size, uin
 template <class W, int NA, bool LAST, bool CPE>
 ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
                             uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
-                            uint32_t mix_sh) {
+                            uint32_t mix_sh, uint32_t na_rt) {
+    /* NA != 0: exactly NA taps, int32 coefficients (unpcBlock4/5/6/8). NA == 0: the general form for the
+     * wave-uniform order na_rt (0..16, 31) on NR = 16 register taps, coefficients wrapped to int16. */
+    constexpr bool GEN = NA == 0;
+    constexpr int NR = GEN ? 16 : NA;
+    const uint32_t na = GEN ? na_rt : (uint32_t)NA;
     constexpr uint32_t BIAS = 0x80000000u;
     const uint32_t kb = cfg.kb;
     const uint32_t wb = (1u << kb) - 1u;
@@ -275,12 +282,13 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
     const int32_t den_half = den_shift ? (int32_t)(1u << (den_shift - 1u)) : 0;
     const uint32_t rnd_neg = (1u << den_shift) - 1u;
 
-    int32_t coef[NA];
-    uint32_t hb[NA + 1]; /* hb[j] = out[i-1-j] ^ BIAS: |a - b| of biased values is one unsigned sad */
+    int32_t coef[NR];
+    uint32_t hb[NR + 1]; /* hb[j] = out[i-1-j] ^ BIAS: |a - b| of biased values is one unsigned sad */
 #pragma unroll
-    for (int j = 0; j < NA; ++j) coef[j] = (int32_t)(int16_t)bits.get(hdr_pos + 16u + 16u * (uint32_t)j, 16);
+    for (int j = 0; j < NR; ++j)
+        coef[j] = (!GEN || ((uint32_t)j < na && na != 31)) ? (int32_t)(int16_t)bits.get(hdr_pos + 16u + 16u * (uint32_t)j, 16) : 0;
 #pragma unroll
-    for (int j = 0; j <= NA; ++j) hb[j] = BIAS;
+    for (int j = 0; j <= NR; ++j) hb[j] = BIAS;
     uint32_t held = 0; /* mono: low half of the dword under construction */
     int32_t u_next = 0;
     if (LAST && CPE) u_next = *wv.u_row(0);
@@ -328,13 +336,20 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
 
         /* ---- one predictor step (UnpcBlock, predictor.go:45-94) ------------------------------------------------ */
         int32_t o;
-        if (i <= (uint32_t)NA) { /* scalar test: out[0] = pc1[0], then the warm-up (predictor.go:53,76-79) */
-            o = i == 0 ? del : sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
+        if (i == 0 || (GEN && na == 0)) { /* scalar tests: out[0] = pc1[0]; numActive 0 copies (predictor.go:53-61) */
+            o = del;
+        } else if (i <= na || (GEN && na == 31)) { /* warm-up; every step of delta mode (31): predictor.go:63-79 */
+            o = sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
         } else {
             /* unpcBlock4/5/6/8 (predictor.go:99-618): taps walked from the highest down. The adaptation is
              * sign-normalised: D0 = |del| shrinks by t_j = (NA-j) * ((|d_j| + rnd) >> denShift) tap after tap and
              * tap j adapts while the running total S_j of the taps above it is still below D0. */
-            const uint32_t topb = hb[NA];
+            uint32_t topb = hb[NR];
+            if (GEN) {
+#pragma unroll
+                for (int j = 1; j < NR; ++j)
+                    if (na == (uint32_t)j) topb = hb[j]; /* scalar branch: na is wave-uniform */
+            }
             const bool neg = del < 0;
             const uint32_t big_d0 = (uint32_t)(neg ? -del : del);
             const uint32_t rnd = neg ? rnd_neg : 0u;
@@ -344,21 +359,22 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
             int32_t dot = 0;
             uint32_t run = 0;
 #pragma unroll
-            for (int j = NA - 1; j >= 0; --j) {
+            for (int j = NR - 1; j >= 0; --j) {
+                if (GEN && (uint32_t)j >= na) continue; /* scalar branch: taps the order does not have */
                 const int32_t d = (int32_t)(topb - hb[j]); /* top - out[i-1-j]; the bias cancels */
                 dot += ALAC_MUL24(coef[j], d);             /* uses coef[j] before its update */
                 const int32_t sd = ALAC_SIGN(d);
                 const int32_t delta = (int32_t)(((uint32_t)sd ^ nmask) + pm);
                 const uint32_t q = ALAC_SAD(topb, hb[j], rnd) >> den_shift;
                 const int32_t step = run < big_d0 ? delta : 0; /* a select of two ready values: no branch */
-                coef[j] += step;
-                run += (uint32_t)ALAC_MUL24((int32_t)q, NA - j);
+                coef[j] = GEN ? (int32_t)(int16_t)(coef[j] + step) : coef[j] + step; /* predictor.go:664,675 */
+                run += (uint32_t)ALAC_MUL24((int32_t)q, (int32_t)na - j);
             }
             const int32_t acc = den_half - dot;
             o = sext_cs(del + (int32_t)(topb ^ BIAS) + (acc >> den_shift), chan_shift);
         }
 #pragma unroll
-        for (int j = NA; j >= 1; --j) hb[j] = hb[j - 1];
+        for (int j = NR; j >= 1; --j) hb[j] = hb[j - 1];
         hb[0] = (uint32_t)o ^ BIAS;
 
         /* ---- hand-off / unmix / PCM ---------------------------------------------------------------------------- */
@@ -394,10 +410,11 @@ ALAC_DEV void regular_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits
                                uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
                                int32_t mix_res, uint32_t mix_sh) {
     switch (na) {
-        case 4: regular_phase<W, 4, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh); break;
-        case 5: regular_phase<W, 5, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh); break;
-        case 6: regular_phase<W, 6, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh); break;
-        default: regular_phase<W, 8, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh); break;
+        case 4: regular_phase<W, 4, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na); break;
+        case 5: regular_phase<W, 5, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na); break;
+        case 6: regular_phase<W, 6, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na); break;
+        case 8: regular_phase<W, 8, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na); break;
+        default: regular_phase<W, 0, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na); break;
     }
 }
 

@@ -335,7 +335,7 @@ struct alacgpu_decoder {
 namespace {
 
 /* upper bound on the waves of a batch: every key present may end in one partly filled wave */
-size_t max_waves(size_t n, uint32_t ppw) { return (n + ppw - 1) / ppw + std::min<size_t>(n, 48); }
+size_t max_waves(size_t n, uint32_t ppw) { return (n + ppw - 1) / ppw + std::min<size_t>(n, 18 * 18 + 8); }
 
 /* Packets per wave. The lock-step loop is a dependent chain that one wave issues at ~1 instruction per 4-5
  * cycles, so the machine is filled by MORE WAVES, not fuller ones: below ~2 resident waves per SIMD a batch is
