@@ -337,16 +337,17 @@ namespace {
 /* upper bound on the waves of a batch: every key present may end in one partly filled wave */
 size_t max_waves(size_t n, uint32_t ppw) { return (n + ppw - 1) / ppw + std::min<size_t>(n, 18 * 18 + 8); }
 
-/* Packets per wave. The lock-step loop is a dependent chain that one wave issues at ~1 instruction per 4-5
- * cycles, so the machine is filled by MORE WAVES, not fuller ones: below ~2 resident waves per SIMD a batch is
- * spread over narrower waves (a half-empty wave costs the same issue slots, but the slots were idle anyway). */
+/* Packets per wave. A VALU instruction costs the SIMD the same 4 cycles whether 64 lanes or 8 are live, and one
+ * wave per SIMD already saturates it (measured: two half-full waves per SIMD are 1.6x SLOWER than one full wave).
+ * So waves are kept full while there are at least as many of them as SIMDs (256 CUs x 4); only a smaller batch is
+ * spread over narrower waves, to use SIMDs that would otherwise idle. */
 uint32_t pick_ppw(size_t n) {
     if (const char* e = getenv("ALACGPU_PPW")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 64) return (uint32_t)v;
     }
     uint32_t ppw = kWave;
-    while (ppw > 1 && n / ppw < 2048) ppw >>= 1;
+    while (ppw > 1 && n / ppw < 1024) ppw >>= 1;
     return ppw;
 }
 
