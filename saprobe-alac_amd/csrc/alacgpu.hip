@@ -154,45 +154,76 @@ struct GpuWave {
     ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * ppw; }
 };
 
+/* Sort-key histogram of one 256-thread block in LDS; only the keys the block saw go to the global counters
+ * (a batch has a dozen distinct keys: per-packet global atomics on them serialise). */
 __global__ void __launch_bounds__(256)
 alac_classify(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
               const uint32_t* __restrict__ sizes, uint32_t n, uint16_t* __restrict__ keys, Plan* plan) {
+    __shared__ uint32_t hist[kKeys];
+    for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint8_t* p = blob + offsets[i];
-    uint32_t key = alac::classify_regular(cfg, p, sizes[i]);
-    if (key == alac::KEY_IRREGULAR) key = 1024u + alac::classify_packet(p, sizes[i]);
-    keys[i] = (uint16_t)key;
-    atomicAdd(&plan->count[key], 1u);
-}
-
-__global__ void alac_plan(Plan* plan, uint32_t ppw) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    /* highest key first: irregular packets, then the longest predictors. The kernel ends when its last wave
-     * does, so the slowest waves take the lowest block ids and start first. */
-    uint32_t p = 0, w = 0, nk = 0;
-    for (int k = (int)kKeys - 1; k >= 0; --k) {
-        const uint32_t c = plan->count[k];
-        plan->pkt_start[k] = p;
-        plan->cursor[k] = 0;
-        if (c) {
-            plan->list_key[nk] = (uint32_t)k;
-            plan->list_wave0[nk] = w;
-            ++nk;
-            p += c;
-            w += (c + ppw - 1) / ppw;
-        }
+    if (i < n) {
+        const uint8_t* p = blob + offsets[i];
+        uint32_t key = alac::classify_regular(cfg, p, sizes[i]);
+        if (key == alac::KEY_IRREGULAR) key = 1024u + alac::classify_packet(p, sizes[i]);
+        keys[i] = (uint16_t)key;
+        atomicAdd(&hist[key], 1u);
     }
-    plan->nk = nk;
-    plan->total_waves = w;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x)
+        if (hist[k]) atomicAdd(&plan->count[k], hist[k]);
 }
 
+/* One block: exclusive scan of the key histogram in dispatch order (highest key first: irregular packets, then
+ * the longest predictors; the kernel ends when its last wave does, so the slowest waves get the lowest block ids). */
+__global__ void __launch_bounds__(256) alac_plan(Plan* plan, uint32_t ppw) {
+    __shared__ uint32_t cnt[kKeys];
+    for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x) cnt[k] = plan->count[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t p = 0, w = 0, nk = 0;
+        for (int k = (int)kKeys - 1; k >= 0; --k) {
+            const uint32_t c = cnt[k];
+            cnt[k] = p; /* becomes pkt_start */
+            if (c) {
+                plan->list_key[nk] = (uint32_t)k;
+                plan->list_wave0[nk] = w;
+                ++nk;
+                p += c;
+                w += (c + ppw - 1) / ppw;
+            }
+        }
+        plan->nk = nk;
+        plan->total_waves = w;
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x) {
+        plan->pkt_start[k] = cnt[k];
+        plan->cursor[k] = 0;
+    }
+}
+
+/* Counting-sort scatter. A block reserves one range per key it holds with a single global atomic and hands out
+ * the slots inside it from LDS. The order of packets inside a key is arbitrary (and may differ run to run);
+ * results do not depend on it. */
 __global__ void __launch_bounds__(256)
 alac_scatter(const uint16_t* __restrict__ keys, uint32_t n, Plan* plan, uint32_t* __restrict__ perm) {
+    __shared__ uint32_t hist[kKeys];
+    __shared__ uint32_t base[kKeys];
+    for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = keys[i];
-    perm[plan->pkt_start[k] + atomicAdd(&plan->cursor[k], 1u)] = i;
+    uint32_t key = 0, local = 0;
+    if (i < n) {
+        key = keys[i];
+        local = atomicAdd(&hist[key], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x)
+        if (hist[k]) base[k] = plan->pkt_start[k] + atomicAdd(&plan->cursor[k], hist[k]);
+    __syncthreads();
+    if (i < n) perm[base[key] + local] = i;
 }
 
 __global__ void __launch_bounds__(kWave)
@@ -379,7 +410,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
     HIP_TRY(hipMemsetAsync(plan, 0, sizeof(Plan), dec->stream));
     hipLaunchKernelGGL(alac_classify, dim3(nb), dim3(256), 0, dec->stream, c, d_blob, d_offsets, d_sizes, (uint32_t)n,
                        (uint16_t*)dec->cls.p, plan);
-    hipLaunchKernelGGL(alac_plan, dim3(1), dim3(1), 0, dec->stream, plan, ppw);
+    hipLaunchKernelGGL(alac_plan, dim3(1), dim3(256), 0, dec->stream, plan, ppw);
     hipLaunchKernelGGL(alac_scatter, dim3(nb), dim3(256), 0, dec->stream, (const uint16_t*)dec->cls.p, (uint32_t)n, plan,
                        (uint32_t*)dec->perm.p);
     const uint32_t slot = (uint32_t)(dec->launches % kTimingSlots);
