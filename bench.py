@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--host-entry", action="store_true", help="also time alacgpu_decode_batch (PCIe-inclusive)")
     ap.add_argument("--profile", type=int, default=0, help="synth profile (0 = SURVEY 8d music model)")
     ap.add_argument("--out-stride-pad", type=int, default=0, help="extra bytes between PCM slots (experiments)")
     return ap.parse_args()
@@ -172,6 +173,31 @@ def main():
                "single_thread_value": round(int(cf1.astype(np.int64).sum()) * ch / one_s / 1e6, 2),
                "all_ok": bool((cs == 0).all())}
 
+    # ---- optional: the host entry (alacgpu_decode_batch: re-pack + H2D + kernels + D2H), never `value` ----
+    host_entry = None
+    if args.host_entry and rank == 0:
+        pk_off = np.zeros(P + 1, dtype=np.uint64)
+        pk_off[1:] = np.cumsum(b.sizes.astype(np.uint64))
+        dense = np.empty(int(pk_off[-1]) + 1, dtype=np.uint8)
+        for i in range(P):
+            o = int(b.offsets[i])
+            dense[int(pk_off[i]):int(pk_off[i + 1])] = b.blob[o:o + int(b.sizes[i])]
+        dec.decode_batch(dense, pk_off)  # warm: staging buffers get allocated
+        t0 = time.perf_counter()
+        h_out, h_fr, h_st = dec.decode_batch(dense, pk_off)
+        dt = time.perf_counter() - t0
+        host_entry = {"value": round(samples / dt / 1e6, 2), "unit": "Msamples/s", "seconds": round(dt, 4),
+                      "what": "pageable host blob -> pinned re-pack -> H2D -> kernels -> D2H into pageable PCM",
+                      "bit_exact": bool(np.array_equal(h_out, b.pcm)) and bool((h_st == 0).all())}
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_final", "traffic.json")
+    if (depth, ch, FL, P) == (16, 2, 4096, 65536) and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]  # PMC passes cannot run inside the bench
+        except Exception:
+            traffic = None
+
     if rank == 0:
         value = samples * world * args.steps / elapsed / 1e6
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms == kernel_ms else None
@@ -188,9 +214,10 @@ def main():
                        "sharding": "independent packet ranges, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None,
-                         "traffic": None, "kernel": "alac_decode", "kernel_ms": round(kernel_ms, 4),
+                         "traffic": traffic, "traffic_source": "profiles/r01_final/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)" if traffic else None,
+                         "kernel": "alac_decode", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
-            "cpu_baseline": cpu, "bit_exact": bit_exact, "gen_seconds": round(gen_s, 2),
+            "cpu_baseline": cpu, "bit_exact": bit_exact, "gen_seconds": round(gen_s, 2), "host_entry": host_entry,
         }
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 2)
