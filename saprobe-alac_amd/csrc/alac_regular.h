@@ -52,7 +52,7 @@ ALAC_DEV bool regular_order(uint32_t na) { return na <= 16 || na == 31; }
 
 /* Sort key of a packet; no entropy decoding, reads only the element header. */
 ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32_t size) {
-    if (cfg.bit_depth != 16 || cfg.num_channels > 2 || cfg.aligned16 == 0 || cfg.kb == 0 ||
+    if (cfg.num_channels > 2 || cfg.aligned16 == 0 || cfg.kb == 0 ||
         cfg.frame_length > 65536u || cfg.frame_length <= 32u)
         return KEY_IRREGULAR;
     const Bits bits{pkt, size};
@@ -62,7 +62,12 @@ ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32
     if (cpe ? tag != 1 : !(tag == 0 || tag == 3)) return KEY_IRREGULAR;
     if (bits.get(7, 12) != 0) return KEY_IRREGULAR;
     const uint32_t hdr = bits.get(19, 4);
-    if (hdr & 7u) return KEY_IRREGULAR; /* shift bytes or escape */
+    if (hdr & 1u) return KEY_IRREGULAR; /* escape element */
+    const uint32_t bs = (hdr >> 1) & 3u;
+    if (bs == 3) return KEY_IRREGULAR;
+    /* 24-bit products need chanBits <= 23 (16-bit; 20-bit; 24/32-bit with their usual shift bytes) */
+    const uint32_t chan_bits = cfg.bit_depth - 8u * bs + (cpe ? 1u : 0u);
+    if (chan_bits < 1 || chan_bits > 23 || cfg.bit_depth < 8u * bs) return KEY_IRREGULAR;
     uint32_t pos = 23;
     uint32_t ns = cfg.frame_length;
     if (hdr >> 3) {
@@ -82,9 +87,10 @@ ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32
         if ((hv >> 12) != 0 || !regular_order(nv)) return KEY_IRREGULAR;
         pos += 16u + 16u * nv;
     }
-    /* header must be wholly inside the packet and the entropy stream must start inside it (anything
-     * else is an error or panic case: decode_wave reports those) */
-    if ((pos >> 3) >= size) return KEY_IRREGULAR;
+    /* header and shift block must be wholly inside the packet and the entropy stream must start inside it
+     * (anything else is an error or panic case: decode_wave reports those) */
+    const uint64_t ent = (uint64_t)pos + (uint64_t)bs * 8u * (cpe ? 2u : 1u) * ns;
+    if ((ent >> 3) >= size) return KEY_IRREGULAR;
     return nu * 32u + nv;
 }
 
@@ -211,7 +217,7 @@ ALAC_DEV int32_t golomb_slow(const Bits& bits, RegLane<W>& s, uint32_t size, uin
             const uint32_t gb = gpos & 7u;
             const bool five = chan_bits + gb > 32u;
             if ((gpos >> 3) > size || (five && (gpos >> 3) >= size)) err = ST_MALFORMED;
-            n = (uint32_t)(bits.window(gpos) >> (64u - chan_bits)); /* chan_bits is 16 or 17 here */
+            n = (uint32_t)(bits.window(gpos) >> (64u - chan_bits)); /* chan_bits is 1..23 here */
             pos += 9u + chan_bits;
         } else {
             const uint32_t v = (w << (n + 1u)) >> (32u - k);
@@ -269,8 +275,9 @@ ALAC_DEV int32_t golomb_slow(const Bits& bits, RegLane<W>& s, uint32_t size, uin
 template <class W, int NA, bool LAST, bool CPE>
 ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
                             uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
-                            uint32_t mix_sh, uint32_t na_rt) {
-    /* NA != 0: exactly NA taps, int32 coefficients (unpcBlock4/5/6/8). NA == 0: the general form for the
+                            uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb) {
+    /* shift_pos / sb: start of the shift-byte block and bits per value to merge (0 = none), LAST only.
+     * NA != 0: exactly NA taps, int32 coefficients (unpcBlock4/5/6/8). NA == 0: the general form for the
      * wave-uniform order na_rt (0..16, 31) on NR = 16 register taps, coefficients wrapped to int16. */
     constexpr bool GEN = NA == 0;
     constexpr int NR = GEN ? 16 : NA;
@@ -289,13 +296,24 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
         coef[j] = (!GEN || ((uint32_t)j < na && na != 31)) ? (int32_t)(int16_t)bits.get(hdr_pos + 16u + 16u * (uint32_t)j, 16) : 0;
 #pragma unroll
     for (int j = 0; j <= NR; ++j) hb[j] = BIAS;
-    uint32_t held = 0; /* mono: low half of the dword under construction */
+    uint64_t pk_acc = 0; /* little-endian byte packer: whole dwords go to the stager */
+    uint32_t pk_n = 0;
+    const uint32_t bps = cfg.bps;
+    const uint64_t pk_msk = bps == 4 ? 0xffffffffull : ((1ull << (8u * bps)) - 1ull);
+    const bool merge_any = LAST && wv.any(sb != 0);
     int32_t u_next = 0;
     if (LAST && CPE) u_next = *wv.u_row(0);
 
     for (uint32_t i = 0; i < n_it; ++i) {
         const bool on = i < ns && s.err == 0;
         if ((i & 3u) == 0) s.rd.tick(wv); /* scalar test: bitstream ring refill, 4 steps ahead of need */
+        uint32_t sh_l = 0, sh_r = 0;
+        if (merge_any) {
+            /* both shift values of the frame sit side by side (decoder.go:492-502): one window, fetched early */
+            const uint64_t sw = bits.window(shift_pos + i * (CPE ? 2u : 1u) * sb);
+            sh_l = sb ? (uint32_t)(sw >> (64u - sb)) : 0u;
+            sh_r = (CPE && sb) ? (uint32_t)((sw << sb) >> (64u - sb)) : 0u;
+        }
         int32_t u_pre = 0;
         if (LAST && CPE) {
             /* U hand-off, fetched one step ahead (row n_it <= frame_length exists: the tile ends in spare cells) */
@@ -380,41 +398,64 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
         /* ---- hand-off / unmix / PCM ---------------------------------------------------------------------------- */
         if (!LAST) {
             *wv.u_row(i) = o; /* dead lanes write their own unused cell */
-        } else if (CPE) {
-            const int32_t u = u_pre, vv = o;
-            int32_t l, r;
-            if (mix_res != 0) { /* matrix.go:40-41 */
-                l = u + vv - (ALAC_MUL24(mix_res, vv) >> mix_sh);
-                r = l - vv;
-            } else {
-                l = u;
-                r = vv;
-            }
-            wv.st_push_if(((uint32_t)l & 0xffffu) | ((uint32_t)r << 16), on);
         } else {
-            /* mono 16-bit: two samples per dword (matrix.go:220-232) */
-            if (i & 1u) wv.st_push_if(held | ((uint32_t)o << 16), on);
-            else held = (uint32_t)o & 0xffffu;
+            int32_t l = o, r = 0;
+            if (CPE) {
+                const int32_t u = u_pre, vv = o;
+                if (mix_res != 0) { /* matrix.go:40-41 */
+                    l = u + vv - (ALAC_MUL24(mix_res, vv) >> mix_sh);
+                    r = l - vv;
+                } else {
+                    l = u;
+                    r = vv;
+                }
+            }
+            if (cfg.bit_depth == 20) { /* matrix.go:77-78, 237 */
+                l = (int32_t)((uint32_t)l << 4);
+                r = (int32_t)((uint32_t)r << 4);
+            }
+            if (merge_any) { /* matrix.go:129-132, 266-268: (x << 8*bytesShifted) | shift value */
+                l = (int32_t)((uint32_t)l << sb) | (int32_t)sh_l;
+                r = (int32_t)((uint32_t)r << sb) | (int32_t)sh_r;
+            }
+            if (bps == 2 && CPE) {
+                wv.st_push_if(((uint32_t)l & 0xffffu) | ((uint32_t)r << 16), on);
+            } else {
+                /* generic widths: append bps bytes per sample, emit a dword whenever four are ready (all selects) */
+                pk_acc |= ((uint64_t)(uint32_t)l & pk_msk) << (8u * pk_n);
+                pk_n += on ? bps : 0u;
+                bool emit = pk_n >= 4u;
+                wv.st_push_if((uint32_t)pk_acc, emit);
+                pk_acc = emit ? pk_acc >> 32 : pk_acc;
+                pk_n = emit ? pk_n - 4u : pk_n;
+                if (CPE) {
+                    pk_acc |= ((uint64_t)(uint32_t)r & pk_msk) << (8u * pk_n);
+                    pk_n += on ? bps : 0u;
+                    emit = pk_n >= 4u;
+                    wv.st_push_if((uint32_t)pk_acc, emit);
+                    pk_acc = emit ? pk_acc >> 32 : pk_acc;
+                    pk_n = emit ? pk_n - 4u : pk_n;
+                }
+                /* a lane that is not `on` appended nothing: clear what the OR left above its valid bytes */
+                pk_acc &= pk_n ? ((1ull << (8u * pk_n)) - 1ull) : 0ull;
+            }
         }
         if (LAST) wv.st_step(); /* collective */
     }
-    if (LAST && !CPE) {
-        /* odd frame count: the last sample is still held */
-        if (s.err == 0 && (ns & 1u)) wv.st_tail16((uint16_t)held);
-    }
+    if (LAST) wv.st_tail(pk_acc, s.err == 0 ? pk_n : 0u); /* bytes of the last, incomplete dword */
 }
 
 /* the order switch is scalar: NA is wave-uniform by construction of the waves */
 template <class W, bool LAST, bool CPE>
 ALAC_DEV void regular_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size,
                                uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
-                               int32_t mix_res, uint32_t mix_sh) {
+                               int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb) {
     switch (na) {
-        case 4: regular_phase<W, 4, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na); break;
-        case 5: regular_phase<W, 5, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na); break;
-        case 6: regular_phase<W, 6, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na); break;
-        case 8: regular_phase<W, 8, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na); break;
-        default: regular_phase<W, 0, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na); break;
+        case 4: regular_phase<W, 4, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 5: regular_phase<W, 5, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 6: regular_phase<W, 6, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 8: regular_phase<W, 8, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        default: regular_phase<W, 0, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
     }
 }
 
@@ -451,8 +492,12 @@ ALAC_DEV int32_t decode_regular(W& wv, const DevCfg& cfg, uint32_t key, bool liv
     const uint32_t hdr_v = hdr_u + 16u + 16u * na_u;
     const uint32_t hu = bits.get(hdr_u, 16);
     const uint32_t hv = bits.get(hdr_v, 16);
-    s.pos = cpe ? hdr_v + 16u + 16u * na_v : hdr_v;
-    const uint32_t chan_bits = cfg.bit_depth + (cpe ? 1u : 0u);
+    const uint32_t bs = (bits.get(19, 4) >> 1) & 3u;
+    const uint32_t shift_pos = cpe ? hdr_v + 16u + 16u * na_v : hdr_v; /* decoder.go:289-293, 453-457 */
+    s.pos = shift_pos + bs * 8u * (cpe ? 2u : 1u) * ns;
+    const uint32_t chan_bits = cfg.bit_depth - 8u * bs + (cpe ? 1u : 0u);
+    /* the 16- and 20-bit writers ignore the shift buffer (matrix.go:30,66) */
+    const uint32_t sb = (cfg.bit_depth == 24 || cfg.bit_depth == 32) ? bs * 8u : 0u;
     const uint32_t n_it = wv.max_u32(ns);
     if (live) wv.st_begin(out);
 
@@ -462,8 +507,8 @@ ALAC_DEV int32_t decode_regular(W& wv, const DevCfg& cfg, uint32_t key, bool liv
     s.zrem = 0;
     s.pb = (cfg.pb * ((hu >> 5) & 7u)) / 4u; /* decoder.go:299 */
     s.rd.start(wv, live ? s.pos : 0u);
-    if (cpe) regular_phase_na<W, false, true>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh);
-    else regular_phase_na<W, true, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0);
+    if (cpe) regular_phase_na<W, false, true>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
+    else regular_phase_na<W, true, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
     uint32_t err_chan = 0;
     /* ---- V ---- */
     if (cpe) {
@@ -475,7 +520,7 @@ ALAC_DEV int32_t decode_regular(W& wv, const DevCfg& cfg, uint32_t key, bool liv
         s.zrem = 0;
         s.pb = (cfg.pb * ((hv >> 5) & 7u)) / 4u;
         s.rd.start(wv, (live && s.err == 0) ? s.pos : 0u);
-        regular_phase_na<W, true, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh);
+        regular_phase_na<W, true, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
         if (err_u == 0 && s.err != 0) err_chan = 1;
     }
     if (!live) return 0;

@@ -110,8 +110,10 @@ struct GpuWave {
         s_rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
         wcnt += on ? 1u : 0u;
     }
-    /* 16-bit tail after the last whole dword (mono, odd frame count) */
-    ALAC_DEV void st_tail16(uint16_t h) { *reinterpret_cast<uint16_t*>(my_out + (size_t)wcnt * 4u) = h; }
+    /* bytes of the last, incomplete dword of the stream (after every dword pushed so far) */
+    ALAC_DEV void st_tail(uint64_t acc, uint32_t nbytes) {
+        for (uint32_t b = 0; b < nbytes; ++b) my_out[(size_t)wcnt * 4u + b] = (uint8_t)(acc >> (8u * b));
+    }
     /* Collective. Rows that just completed a 32-dword chunk are written out as 128-B lines: store
      * instruction k covers packets 8k..8k+7, eight lanes x 16 B per packet. Lock step makes `flushed`
      * identical in all full lanes. */

@@ -36,7 +36,9 @@ struct HostWave {
     void st_push_if(uint32_t v, bool on) {
         if (on) st_push(v);
     }
-    void st_tail16(uint16_t h) { memcpy(st_out + 4u * (size_t)st_cnt, &h, 2); }
+    void st_tail(uint64_t acc, uint32_t nbytes) {
+        for (uint32_t b = 0; b < nbytes; ++b) st_out[4u * (size_t)st_cnt + b] = (uint8_t)(acc >> (8u * b));
+    }
     void st_step() {}
     uint32_t st_finish() { return st_cnt; }
     uint32_t ring[32] = {0};
