@@ -156,7 +156,8 @@ def ParseMagicCookie(cookie):
 
 # ---- native library --------------------------------------------------------------------------------------
 def lib_path():
-    return os.path.join(_CSRC, "libalacgpu.so")
+    # ALACGPU_LIB: another build of the same library (kernel A/B experiments under profiles/)
+    return os.environ.get("ALACGPU_LIB") or os.path.join(_CSRC, "libalacgpu.so")
 
 
 def build(force=False):

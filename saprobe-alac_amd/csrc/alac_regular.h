@@ -36,6 +36,11 @@
         (d) = (q)[3];            \
     } while (0)
 #endif
+#ifndef ALAC_PICK
+/* dst = src, opaque to the optimiser on the GPU: a chain of these under scalar tests must stay a chain of
+ * v_mov (written plainly the compiler turns it into an indexed load from a scratch copy of the array) */
+#define ALAC_PICK(dst, src) ((dst) = (src))
+#endif
 #ifndef ALAC_SIGN
 /* -1 / 0 / +1: one v_med3_i32 on the GPU */
 #define ALAC_SIGN(x) (((x) > 0) - ((x) < 0))
@@ -272,6 +277,13 @@ ALAC_DEV int32_t golomb_slow(const Bits& bits, RegLane<W>& s, uint32_t size, uin
  * One channel of a regular element, all lanes in lock step. NA = this channel's predictor order (wave-uniform).
  * LAST: this channel completes the frame (V of a pair, or the mono channel): unmix and emit PCM.
  */
+/* tentative result of the branch-free part of one Golomb sample (see regular_phase) */
+struct GolTent {
+    uint32_t pos2, mean2;
+    int32_t del;
+    bool dec, slow, on, inrun;
+};
+
 template <class W, int NA, bool LAST, bool CPE>
 ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
                             uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
@@ -304,26 +316,16 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
     int32_t u_next = 0;
     if (LAST && CPE) u_next = *wv.u_row(0);
 
-    for (uint32_t i = 0; i < n_it; ++i) {
-        const bool on = i < ns && s.err == 0;
-        if ((i & 3u) == 0) s.rd.tick(wv); /* scalar test: bitstream ring refill, 4 steps ahead of need */
-        uint32_t sh_l = 0, sh_r = 0;
-        if (merge_any) {
-            /* both shift values of the frame sit side by side (decoder.go:492-502): one window, fetched early */
-            const uint64_t sw = bits.window(shift_pos + i * (CPE ? 2u : 1u) * sb);
-            sh_l = sb ? (uint32_t)(sw >> (64u - sb)) : 0u;
-            sh_r = (CPE && sb) ? (uint32_t)((sw << sb) >> (64u - sb)) : 0u;
-        }
-        int32_t u_pre = 0;
-        if (LAST && CPE) {
-            /* U hand-off, fetched one step ahead (row n_it <= frame_length exists: the tile ends in spare cells) */
-            u_pre = u_next;
-            u_next = *wv.u_row(i + 1u);
-        }
-
-        /* ---- one residual (DynDecomp, golomb.go:167-247), common path without branches ---------------------- */
-        const bool inrun = s.zrem != 0;
-        const bool dec = on && !inrun;
+    /* ---- one residual (DynDecomp, golomb.go:167-247) in two halves ------------------------------------------
+     * tentative(): pure ALU, no branch, no state change. commit(): the one rare branch (escape code, start of a
+     * zero run, overrun), then the state update by selects and the reader slide. Splitting it lets the main
+     * loop put the tentative half of sample i+1 in the same basic block as the predictor taps of sample i: two
+     * independent dependency chains for the scheduler to interleave (a lone wave issues a dependent VALU op every
+     * ~8.3 cycles, an independent one every ~4.8: profiles/microbench). */
+    auto tentative = [&](uint32_t i, GolTent& t) {
+        t.on = i < ns && s.err == 0;
+        t.inrun = s.zrem != 0;
+        t.dec = t.on && !t.inrun;
         uint32_t m = s.mean >> 9;
         const uint32_t k = umin(31u - clz32(m + 3u), kb);
         m = (1u << k) - 1u;
@@ -333,114 +335,177 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
         const bool big = v >= 2;
         const uint32_t n = pre * m + (big ? v - 1u : 0u);
         const uint32_t nd = n + s.zmode;
-        uint32_t mean2 = s.pb * nd + s.mean - ((s.pb * s.mean) >> 9); /* golomb.go:215 */
-        if (n > 0xffffu) mean2 = 0xffffu;
-        const bool slow = dec && (s.pos >= s.max_pos || pre >= 9 || ((mean2 << 2) < 512u && i + 1u < ns));
+        t.mean2 = s.pb * nd + s.mean - ((s.pb * s.mean) >> 9); /* golomb.go:215 */
+        if (n > 0xffffu) t.mean2 = 0xffffu;
+        t.slow = t.dec && (s.pos >= s.max_pos || pre >= 9 || ((t.mean2 << 2) < 512u && i + 1u < ns));
         const int32_t half = (int32_t)((nd + 1u) >> 1); /* golomb.go:206-209 */
-        int32_t del = (nd & 1u) ? -half : half;
-        if (inrun) del = 0;
-        if (wv.any(slow)) {
-            if (slow) {
+        t.del = t.inrun ? 0 : ((nd & 1u) ? -half : half);
+        t.pos2 = s.pos + pre + k + (big ? 1u : 0u); /* prefix + 1, then k bits (v >= 2) or k - 1 */
+    };
+    auto commit = [&](uint32_t i, GolTent& t) -> int32_t {
+        int32_t del = t.del;
+        if (wv.any(t.slow)) {
+            if (t.slow) {
                 del = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns);
                 s.rd.reseek(wv, s.pos);
             }
         }
-        const bool commit = dec && !slow;
-        s.pos = commit ? s.pos + pre + k + (big ? 1u : 0u) : s.pos; /* prefix + 1, then k bits (v >= 2) or k - 1 */
-        s.mean = commit ? mean2 : s.mean;
-        s.zmode = commit ? 0u : s.zmode;
-        s.zrem = (on && inrun) ? s.zrem - 1u : s.zrem;
+        const bool ok = t.dec && !t.slow;
+        s.pos = ok ? t.pos2 : s.pos;
+        s.mean = ok ? t.mean2 : s.mean;
+        s.zmode = ok ? 0u : s.zmode;
+        s.zrem = (t.on && t.inrun) ? s.zrem - 1u : s.zrem;
         s.rd.slide(wv, s.pos);
-
-        /* ---- one predictor step (UnpcBlock, predictor.go:45-94) ------------------------------------------------ */
-        int32_t o;
-        if (i == 0 || (GEN && na == 0)) { /* scalar tests: out[0] = pc1[0]; numActive 0 copies (predictor.go:53-61) */
-            o = del;
-        } else if (i <= na || (GEN && na == 31)) { /* warm-up; every step of delta mode (31): predictor.go:63-79 */
-            o = sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
-        } else {
-            /* unpcBlock4/5/6/8 (predictor.go:99-618): taps walked from the highest down. The adaptation is
-             * sign-normalised: D0 = |del| shrinks by t_j = (NA-j) * ((|d_j| + rnd) >> denShift) tap after tap and
-             * tap j adapts while the running total S_j of the taps above it is still below D0. */
-            uint32_t topb = hb[NR];
-            if (GEN) {
+        return del;
+    };
+    /* ---- predictor step for i > na (UnpcBlock, predictor.go:99-684) -------------------------------------------
+     * Taps walked from the highest down. The adaptation is sign-normalised: D0 = |del| shrinks by
+     * t_j = (na-j) * ((|d_j| + rnd) >> denShift) tap after tap and tap j adapts while the running total of the
+     * taps above it is still below D0. */
+    auto predict = [&](int32_t del) -> int32_t {
+        uint32_t topb = hb[NR];
+        if (GEN) {
 #pragma unroll
-                for (int j = 1; j < NR; ++j)
-                    if (na == (uint32_t)j) topb = hb[j]; /* scalar branch: na is wave-uniform */
-            }
-            const bool neg = del < 0;
-            const uint32_t big_d0 = (uint32_t)(neg ? -del : del);
-            const uint32_t rnd = neg ? rnd_neg : 0u;
-            /* delta_j = sign(del) * -sign(d_j) as (sd ^ nmask) + pm: identity for del < 0, negation otherwise */
-            const uint32_t nmask = neg ? 0u : 0xffffffffu;
-            const uint32_t pm = neg ? 0u : 1u;
-            int32_t dot = 0;
-            uint32_t run = 0;
-#pragma unroll
-            for (int j = NR - 1; j >= 0; --j) {
-                if (GEN && (uint32_t)j >= na) continue; /* scalar branch: taps the order does not have */
-                const int32_t d = (int32_t)(topb - hb[j]); /* top - out[i-1-j]; the bias cancels */
-                dot += ALAC_MUL24(coef[j], d);             /* uses coef[j] before its update */
-                const int32_t sd = ALAC_SIGN(d);
-                const int32_t delta = (int32_t)(((uint32_t)sd ^ nmask) + pm);
-                const uint32_t q = ALAC_SAD(topb, hb[j], rnd) >> den_shift;
-                const int32_t step = run < big_d0 ? delta : 0; /* a select of two ready values: no branch */
-                coef[j] = GEN ? (int32_t)(int16_t)(coef[j] + step) : coef[j] + step; /* predictor.go:664,675 */
-                run += (uint32_t)ALAC_MUL24((int32_t)q, (int32_t)na - j);
-            }
-            const int32_t acc = den_half - dot;
-            o = sext_cs(del + (int32_t)(topb ^ BIAS) + (acc >> den_shift), chan_shift);
+            for (int j = 1; j < NR; ++j)
+                if (na == (uint32_t)j) ALAC_PICK(topb, hb[j]); /* scalar branch: na is wave-uniform */
         }
+        const bool neg = del < 0;
+        const uint32_t big_d0 = (uint32_t)(neg ? -del : del);
+        const uint32_t rnd = neg ? rnd_neg : 0u;
+        /* delta_j = sign(del) * -sign(d_j) as (sd ^ nmask) + pm: identity for del < 0, negation otherwise */
+        const uint32_t nmask = neg ? 0u : 0xffffffffu;
+        const uint32_t pm = neg ? 0u : 1u;
+        int32_t dot = 0;
+        uint32_t run = 0;
+#pragma unroll
+        for (int j = NR - 1; j >= 0; --j) {
+            if (GEN && (uint32_t)j >= na) continue; /* scalar branch: taps the order does not have */
+            const int32_t d = (int32_t)(topb - hb[j]); /* top - out[i-1-j]; the bias cancels */
+            dot += ALAC_MUL24(coef[j], d);             /* uses coef[j] before its update */
+            const int32_t sd = ALAC_SIGN(d);
+            const int32_t delta = (int32_t)(((uint32_t)sd ^ nmask) + pm);
+            const uint32_t q = ALAC_SAD(topb, hb[j], rnd) >> den_shift;
+            const int32_t step = run < big_d0 ? delta : 0; /* a select of two ready values: no branch */
+            coef[j] = GEN ? (int32_t)(int16_t)(coef[j] + step) : coef[j] + step; /* predictor.go:664,675 */
+            run += (uint32_t)ALAC_MUL24((int32_t)q, (int32_t)na - j);
+        }
+        const int32_t acc = den_half - dot;
+        return sext_cs(del + (int32_t)(topb ^ BIAS) + (acc >> den_shift), chan_shift);
+    };
+    /* ---- history, hand-off / unmix / PCM of sample i ------------------------------------------------------------ */
+    auto emit = [&](uint32_t i, int32_t o, bool on, int32_t u_pre, uint32_t sh_l, uint32_t sh_r) {
 #pragma unroll
         for (int j = NR; j >= 1; --j) hb[j] = hb[j - 1];
         hb[0] = (uint32_t)o ^ BIAS;
-
-        /* ---- hand-off / unmix / PCM ---------------------------------------------------------------------------- */
         if (!LAST) {
+#ifndef ALAC_EXP_NO_U_STORE
             *wv.u_row(i) = o; /* dead lanes write their own unused cell */
-        } else {
-            int32_t l = o, r = 0;
-            if (CPE) {
-                const int32_t u = u_pre, vv = o;
-                if (mix_res != 0) { /* matrix.go:40-41 */
-                    l = u + vv - (ALAC_MUL24(mix_res, vv) >> mix_sh);
-                    r = l - vv;
-                } else {
-                    l = u;
-                    r = vv;
-                }
-            }
-            if (cfg.bit_depth == 20) { /* matrix.go:77-78, 237 */
-                l = (int32_t)((uint32_t)l << 4);
-                r = (int32_t)((uint32_t)r << 4);
-            }
-            if (merge_any) { /* matrix.go:129-132, 266-268: (x << 8*bytesShifted) | shift value */
-                l = (int32_t)((uint32_t)l << sb) | (int32_t)sh_l;
-                r = (int32_t)((uint32_t)r << sb) | (int32_t)sh_r;
-            }
-            if (bps == 2 && CPE) {
-                wv.st_push_if(((uint32_t)l & 0xffffu) | ((uint32_t)r << 16), on);
+#else
+            asm volatile("" ::"v"(o));
+#endif
+            return;
+        }
+        int32_t l = o, r = 0;
+        if (CPE) {
+            const int32_t u = u_pre, vv = o;
+            if (mix_res != 0) { /* matrix.go:40-41 */
+                l = u + vv - (ALAC_MUL24(mix_res, vv) >> mix_sh);
+                r = l - vv;
             } else {
-                /* generic widths: append bps bytes per sample, emit a dword whenever four are ready (all selects) */
-                pk_acc |= ((uint64_t)(uint32_t)l & pk_msk) << (8u * pk_n);
-                pk_n += on ? bps : 0u;
-                bool emit = pk_n >= 4u;
-                wv.st_push_if((uint32_t)pk_acc, emit);
-                pk_acc = emit ? pk_acc >> 32 : pk_acc;
-                pk_n = emit ? pk_n - 4u : pk_n;
-                if (CPE) {
-                    pk_acc |= ((uint64_t)(uint32_t)r & pk_msk) << (8u * pk_n);
-                    pk_n += on ? bps : 0u;
-                    emit = pk_n >= 4u;
-                    wv.st_push_if((uint32_t)pk_acc, emit);
-                    pk_acc = emit ? pk_acc >> 32 : pk_acc;
-                    pk_n = emit ? pk_n - 4u : pk_n;
-                }
-                /* a lane that is not `on` appended nothing: clear what the OR left above its valid bytes */
-                pk_acc &= pk_n ? ((1ull << (8u * pk_n)) - 1ull) : 0ull;
+                l = u;
+                r = vv;
             }
         }
+        if (cfg.bit_depth == 20) { /* matrix.go:77-78, 237 */
+            l = (int32_t)((uint32_t)l << 4);
+            r = (int32_t)((uint32_t)r << 4);
+        }
+        if (merge_any) { /* matrix.go:129-132, 266-268: (x << 8*bytesShifted) | shift value */
+            l = (int32_t)((uint32_t)l << sb) | (int32_t)sh_l;
+            r = (int32_t)((uint32_t)r << sb) | (int32_t)sh_r;
+        }
+        if (bps == 2 && CPE) {
+            wv.st_push_if(((uint32_t)l & 0xffffu) | ((uint32_t)r << 16), on);
+        } else {
+            /* generic widths: append bps bytes per sample, emit a dword whenever four are ready (all selects) */
+            pk_acc |= ((uint64_t)(uint32_t)l & pk_msk) << (8u * pk_n);
+            pk_n += on ? bps : 0u;
+            bool em = pk_n >= 4u;
+            wv.st_push_if((uint32_t)pk_acc, em);
+            pk_acc = em ? pk_acc >> 32 : pk_acc;
+            pk_n = em ? pk_n - 4u : pk_n;
+            if (CPE) {
+                pk_acc |= ((uint64_t)(uint32_t)r & pk_msk) << (8u * pk_n);
+                pk_n += on ? bps : 0u;
+                em = pk_n >= 4u;
+                wv.st_push_if((uint32_t)pk_acc, em);
+                pk_acc = em ? pk_acc >> 32 : pk_acc;
+                pk_n = em ? pk_n - 4u : pk_n;
+            }
+            /* a lane that is not `on` appended nothing: clear what the OR left above its valid bytes */
+            pk_acc &= pk_n ? ((1ull << (8u * pk_n)) - 1ull) : 0ull;
+        }
+    };
+    /* per-step memory prefetches of sample i: shift values (24/32-bit) and the U hand-off, one step ahead */
+    auto fetch = [&](uint32_t i, int32_t& u_pre, uint32_t& sh_l, uint32_t& sh_r) {
+        sh_l = sh_r = 0;
+        if (merge_any) {
+            /* both shift values of the frame sit side by side (decoder.go:492-502): one window */
+            const uint64_t sw = bits.window(shift_pos + i * (CPE ? 2u : 1u) * sb);
+            sh_l = sb ? (uint32_t)(sw >> (64u - sb)) : 0u;
+            sh_r = (CPE && sb) ? (uint32_t)((sw << sb) >> (64u - sb)) : 0u;
+        }
+        u_pre = 0;
+        if (LAST && CPE) {
+            /* row n_it <= frame_length exists: the tile ends in spare cells */
+            u_pre = u_next;
+#ifndef ALAC_EXP_NO_U_LOAD
+            u_next = *wv.u_row(i + 1u);
+#else
+            u_next = (int32_t)i;
+#endif
+        }
+    };
+
+    /* ---- head: out[0] = pc1[0], warm-up (predictor.go:53-79); also the whole block for copy / delta mode ------ */
+    const bool simple_all = GEN && (na == 0 || na == 31);
+    const uint32_t head = simple_all ? n_it : umin(na + 1u, n_it);
+    uint32_t i = 0;
+    for (; i < head; ++i) {
+        if ((i & 3u) == 0) s.rd.tick(wv); /* scalar test: bitstream ring refill, 4 steps ahead of need */
+        int32_t u_pre;
+        uint32_t sh_l, sh_r;
+        fetch(i, u_pre, sh_l, sh_r);
+        GolTent t;
+        tentative(i, t);
+        const int32_t del = commit(i, t);
+        const int32_t o = (i == 0 || (GEN && na == 0)) ? del : sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
+        emit(i, o, t.on, u_pre, sh_l, sh_r);
+#ifndef ALAC_EXP_NO_FLUSH
         if (LAST) wv.st_step(); /* collective */
+#endif
+    }
+    /* ---- main loop, software-pipelined by one sample: predictor of sample i with the Golomb code of i+1 -------- */
+    if (i < n_it) {
+        GolTent t;
+        tentative(i, t);
+        int32_t del = commit(i, t);
+        bool on = t.on;
+        for (; i < n_it; ++i) {
+            if ((i & 3u) == 0) s.rd.tick(wv);
+            int32_t u_pre;
+            uint32_t sh_l, sh_r;
+            fetch(i, u_pre, sh_l, sh_r);
+            GolTent tn;
+            tentative(i + 1u, tn);         /* chain 1: entropy code of the next sample (i + 1 >= ns: a dead step) */
+            const int32_t o = predict(del); /* chain 2: taps of this sample */
+            emit(i, o, on, u_pre, sh_l, sh_r);
+            del = commit(i + 1u, tn);
+            on = tn.on;
+#ifndef ALAC_EXP_NO_FLUSH
+            if (LAST) wv.st_step(); /* collective */
+#endif
+        }
     }
     if (LAST) wv.st_tail(pk_acc, s.err == 0 ? pk_n : 0u); /* bytes of the last, incomplete dword */
 }

@@ -34,6 +34,7 @@ __device__ __forceinline__ int32_t alac_sign_med3(int32_t x) {
     return r;
 }
 #define ALAC_SIGN(x) alac_sign_med3(x)
+#define ALAC_PICK(dst, src) asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(src))
 typedef uint32_t alac_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 #define ALAC_LOAD4(q, a, b, c, d)                                                       \
     do {                                                                                \
