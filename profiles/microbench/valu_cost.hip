@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 #include <algorithm>
+#include <cstdlib>
 
 #define REP 64
 #define ITER 256
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(64) k64(unsigned* out, unsigned long long* cyc
 
 template <class F>
 static void run(const char* name, F launch) {
-    const int blocks = 1024;
+    const int blocks = getenv("MB_BLOCKS") ? atoi(getenv("MB_BLOCKS")) : 1024;
     unsigned* out;
     unsigned long long* cyc;
     hipMalloc(&out, blocks * 64 * 4);

@@ -293,6 +293,8 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
      * wave-uniform order na_rt (0..16, 31) on NR = 16 register taps, coefficients wrapped to int16. */
     constexpr bool GEN = NA == 0;
     constexpr int NR = GEN ? 16 : NA;
+    /* orders other than 4/5/6/8 run unpcBlockGeneral: int16 coefficients (predictor.go:81-93) */
+    constexpr bool WRAP = !(NA == 4 || NA == 5 || NA == 6 || NA == 8);
     const uint32_t na = GEN ? na_rt : (uint32_t)NA;
     constexpr uint32_t BIAS = 0x80000000u;
     const uint32_t kb = cfg.kb;
@@ -386,7 +388,7 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
             const int32_t delta = (int32_t)(((uint32_t)sd ^ nmask) + pm);
             const uint32_t q = ALAC_SAD(topb, hb[j], rnd) >> den_shift;
             const int32_t step = run < big_d0 ? delta : 0; /* a select of two ready values: no branch */
-            coef[j] = GEN ? (int32_t)(int16_t)(coef[j] + step) : coef[j] + step; /* predictor.go:664,675 */
+            coef[j] = WRAP ? (int32_t)(int16_t)(coef[j] + step) : coef[j] + step; /* predictor.go:664,675 */
             run += (uint32_t)ALAC_MUL24((int32_t)q, (int32_t)na - j);
         }
         const int32_t acc = den_half - dot;
@@ -515,11 +517,24 @@ template <class W, bool LAST, bool CPE>
 ALAC_DEV void regular_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size,
                                uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
                                int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb) {
+    /* one instantiation per order 1..16 (exact tap count, no skips); 0 (copy) and 31 (delta) share the general one */
     switch (na) {
+        case 1: regular_phase<W, 1, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 2: regular_phase<W, 2, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 3: regular_phase<W, 3, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
         case 4: regular_phase<W, 4, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
         case 5: regular_phase<W, 5, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
         case 6: regular_phase<W, 6, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 7: regular_phase<W, 7, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
         case 8: regular_phase<W, 8, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 9: regular_phase<W, 9, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 10: regular_phase<W, 10, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 11: regular_phase<W, 11, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 12: regular_phase<W, 12, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 13: regular_phase<W, 13, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 14: regular_phase<W, 14, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 15: regular_phase<W, 15, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 16: regular_phase<W, 16, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
         default: regular_phase<W, 0, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
     }
 }
