@@ -81,8 +81,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU decode path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run even a single rank joins the group
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", device_id=dev)
 
     P, FL, depth, ch = args.packets, args.frame_length, args.depth, args.channels
@@ -115,7 +117,7 @@ def main():
     def fence():
         dec.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -127,7 +129,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -145,7 +147,7 @@ def main():
             ok = ok and bool(torch.equal(d_out[lo:lo + chunk, :exp.shape[1]], exp))
             del exp
         bit_exact = ok
-        if world > 1:
+        if use_dist:
             t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             bit_exact = bool(t.item())
@@ -223,7 +225,7 @@ def main():
             line["gpu_over_cpu"] = round(value / cpu["value"], 2)
         print(json.dumps(line), flush=True)
     dec.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if bit_exact is False:
         sys.exit(3)
