@@ -222,7 +222,10 @@ ALAC_DEV int32_t golomb_slow(const Bits& bits, RegLane<W>& s, uint32_t size, uin
             const uint32_t gb = gpos & 7u;
             const bool five = chan_bits + gb > 32u;
             if ((gpos >> 3) > size || (five && (gpos >> 3) >= size)) err = ST_MALFORMED;
-            n = (uint32_t)(bits.window(gpos) >> (64u - chan_bits)); /* chan_bits is 1..23 here */
+            const uint64_t w2 = bits.window(gpos);
+        if (chan_bits == 0) n = 0;
+        else if (chan_bits <= 32) n = (uint32_t)(w2 >> (64u - chan_bits));
+        else n = (uint32_t)(w2 >> 31) & ((2u << gb) - 1u); /* numBits 33: only byte 5 survives (golomb.go:90-99) */
             pos += 9u + chan_bits;
         } else {
             const uint32_t v = (w << (n + 1u)) >> (32u - k);
@@ -284,11 +287,25 @@ struct GolTent {
     bool dec, slow, on, inrun;
 };
 
-template <class W, int NA, bool LAST, bool CPE>
+/* what a phase does with the reconstructed samples */
+enum { OUT_UTILE = 0,  /* U of a pair: hand-off tile */
+       OUT_STEREO = 1, /* V of a pair: unmix with U, PCM */
+       OUT_MONO = 2,   /* single channel: PCM */
+       OUT_RAW = 3,    /* int32 samples into this lane's row (split pipeline, alac_split.h) */
+       OUT_NONE = 4 }; /* nothing: entropy scan only */
+
+template <class W, int NA, int OUT, bool NARROW>
 ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
                             uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
-                            uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb) {
-    /* shift_pos / sb: start of the shift-byte block and bits per value to merge (0 = none), LAST only.
+                            uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb, uint32_t mode) {
+    constexpr bool LAST = OUT == OUT_STEREO || OUT == OUT_MONO;
+    constexpr bool CPE = OUT == OUT_STEREO;
+    constexpr bool RAW = OUT == OUT_RAW;
+    constexpr bool SCAN = OUT == OUT_NONE;
+    /* NARROW: chanBits <= 23, so every product fits the 24-bit multipliers and nothing in the adaptation can
+     * wrap; otherwise plain 32-bit arithmetic in the reference's literal form. mode != 0 (per lane): the delta
+     * pre-pass of decoder.go:307-309 runs on the residual stream first.
+     * shift_pos / sb: start of the shift-byte block and bits per value to merge (0 = none), LAST only.
      * NA != 0: exactly NA taps, int32 coefficients (unpcBlock4/5/6/8). NA == 0: the general form for the
      * wave-uniform order na_rt (0..16, 31) on NR = 16 register taps, coefficients wrapped to int16. */
     constexpr bool GEN = NA == 0;
@@ -317,6 +334,15 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
     const bool merge_any = LAST && wv.any(sb != 0);
     int32_t u_next = 0;
     if (LAST && CPE) u_next = *wv.u_row(0);
+    int32_t dprev = 0;
+    const bool mode_any = !SCAN && wv.any(mode != 0);
+    /* decoder.go:307-309: UnpcBlock(numActive 31, denShift 0) over the residuals before the coefficient pass */
+    auto prepass = [&](uint32_t idx, int32_t del) -> int32_t {
+        if (!mode_any) return del;
+        const int32_t dd = idx == 0 ? del : sext_cs(del + dprev, chan_shift);
+        dprev = mode != 0 ? dd : dprev;
+        return mode != 0 ? dd : del;
+    };
 
     /* ---- one residual (DynDecomp, golomb.go:167-247) in two halves ------------------------------------------
      * tentative(): pure ALU, no branch, no state change. commit(): the one rare branch (escape code, start of a
@@ -365,6 +391,39 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
      * t_j = (na-j) * ((|d_j| + rnd) >> denShift) tap after tap and tap j adapts while the running total of the
      * taps above it is still below D0. */
     auto predict = [&](int32_t del) -> int32_t {
+        if (!NARROW) {
+            /* literal form of predictor.go:99-684 on 32-bit arithmetic */
+            int32_t top = (int32_t)(hb[NR] ^ BIAS);
+            if (GEN) {
+#pragma unroll
+                for (int j = 1; j < NR; ++j)
+                    if (na == (uint32_t)j) ALAC_PICK(top, (int32_t)(hb[j] ^ BIAS));
+            }
+            int32_t d[NR];
+            int32_t acc = den_half;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                d[j] = top - (int32_t)(hb[j] ^ BIAS);
+                if (!GEN || (uint32_t)j < na) acc -= coef[j] * d[j];
+            }
+            const int32_t o = sext_cs(del + top + (acc >> den_shift), chan_shift);
+            if (del != 0) {
+                const int32_t sg = del > 0 ? 1 : -1;
+                int32_t del0 = del;
+                bool go = true;
+#pragma unroll
+                for (int j = NR - 1; j >= 0; --j) {
+                    if (GEN && (uint32_t)j >= na) continue;
+                    const int32_t sgn = sg > 0 ? sign_of(d[j]) : -sign_of(d[j]);
+                    int32_t cj = coef[j] - sgn;
+                    if (WRAP) cj = (int32_t)(int16_t)cj;
+                    coef[j] = go ? cj : coef[j];
+                    del0 -= go ? (int32_t)(na - (uint32_t)j) * ((sgn * d[j]) >> den_shift) : 0;
+                    go = go && (sg > 0 ? del0 > 0 : del0 < 0);
+                }
+            }
+            return o;
+        }
         uint32_t topb = hb[NR];
         if (GEN) {
 #pragma unroll
@@ -399,6 +458,10 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
 #pragma unroll
         for (int j = NR; j >= 1; --j) hb[j] = hb[j - 1];
         hb[0] = (uint32_t)o ^ BIAS;
+        if (RAW) {
+            wv.st_push_if((uint32_t)o, on); /* one int32 sample per step into the lane's row */
+            return;
+        }
         if (!LAST) {
 #ifndef ALAC_EXP_NO_U_STORE
             *wv.u_row(i) = o; /* dead lanes write their own unused cell */
@@ -470,7 +533,7 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
     };
 
     /* ---- head: out[0] = pc1[0], warm-up (predictor.go:53-79); also the whole block for copy / delta mode ------ */
-    const bool simple_all = GEN && (na == 0 || na == 31);
+    const bool simple_all = SCAN || (GEN && (na == 0 || na == 31));
     const uint32_t head = simple_all ? n_it : umin(na + 1u, n_it);
     uint32_t i = 0;
     for (; i < head; ++i) {
@@ -480,18 +543,20 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
         fetch(i, u_pre, sh_l, sh_r);
         GolTent t;
         tentative(i, t);
-        const int32_t del = commit(i, t);
+        int32_t del = commit(i, t);
+        if (SCAN) continue; /* entropy scan: only the position matters */
+        del = prepass(i, del);
         const int32_t o = (i == 0 || (GEN && na == 0)) ? del : sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
         emit(i, o, t.on, u_pre, sh_l, sh_r);
 #ifndef ALAC_EXP_NO_FLUSH
-        if (LAST) wv.st_step(); /* collective */
+        if (LAST || RAW) wv.st_step(); /* collective */
 #endif
     }
     /* ---- main loop, software-pipelined by one sample: predictor of sample i with the Golomb code of i+1 -------- */
     if (i < n_it) {
         GolTent t;
         tentative(i, t);
-        int32_t del = commit(i, t);
+        int32_t del = prepass(i, commit(i, t));
         bool on = t.on;
         for (; i < n_it; ++i) {
             if ((i & 3u) == 0) s.rd.tick(wv);
@@ -502,10 +567,10 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
             tentative(i + 1u, tn);         /* chain 1: entropy code of the next sample (i + 1 >= ns: a dead step) */
             const int32_t o = predict(del); /* chain 2: taps of this sample */
             emit(i, o, on, u_pre, sh_l, sh_r);
-            del = commit(i + 1u, tn);
+            del = prepass(i + 1u, commit(i + 1u, tn));
             on = tn.on;
 #ifndef ALAC_EXP_NO_FLUSH
-            if (LAST) wv.st_step(); /* collective */
+            if (LAST || RAW) wv.st_step(); /* collective */
 #endif
         }
     }
@@ -513,29 +578,52 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
 }
 
 /* the order switch is scalar: NA is wave-uniform by construction of the waves */
-template <class W, bool LAST, bool CPE>
+template <class W, int OUT, bool NARROW>
 ALAC_DEV void regular_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size,
                                uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
-                               int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb) {
+                               int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb, uint32_t mode) {
     /* one instantiation per order 1..16 (exact tap count, no skips); 0 (copy) and 31 (delta) share the general one */
     switch (na) {
-        case 1: regular_phase<W, 1, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 2: regular_phase<W, 2, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 3: regular_phase<W, 3, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 4: regular_phase<W, 4, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 5: regular_phase<W, 5, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 6: regular_phase<W, 6, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 7: regular_phase<W, 7, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 8: regular_phase<W, 8, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 9: regular_phase<W, 9, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 10: regular_phase<W, 10, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 11: regular_phase<W, 11, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 12: regular_phase<W, 12, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 13: regular_phase<W, 13, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 14: regular_phase<W, 14, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 15: regular_phase<W, 15, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        case 16: regular_phase<W, 16, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
-        default: regular_phase<W, 0, LAST, CPE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb); break;
+        case 1: regular_phase<W, 1, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 2: regular_phase<W, 2, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 3: regular_phase<W, 3, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 4: regular_phase<W, 4, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 5: regular_phase<W, 5, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 6: regular_phase<W, 6, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 7: regular_phase<W, 7, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 8: regular_phase<W, 8, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 9: regular_phase<W, 9, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 10: regular_phase<W, 10, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 11: regular_phase<W, 11, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 12: regular_phase<W, 12, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 13: regular_phase<W, 13, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 14: regular_phase<W, 14, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 15: regular_phase<W, 15, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        case 16: regular_phase<W, 16, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+        default: regular_phase<W, 0, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
+    }
+}
+
+/* Entropy scan of one channel for decode_wave<..., SCAN>: the lean Golomb loop with nothing behind it. */
+template <class W>
+ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const Bits& bits, const uint8_t* pkt, uint32_t size, bool go,
+                           uint32_t& pos, uint32_t ns, uint32_t pb_local, uint32_t chan_bits, int32_t& err) {
+    RegLane<W> s;
+    s.rd.init(pkt, size);
+    s.err = 0;
+    s.max_pos = size * 8u;
+    s.pos = go ? pos : 0u;
+    s.mean = cfg.mb;
+    s.zmode = 0;
+    s.zrem = 0;
+    s.pb = pb_local;
+    const uint32_t my_ns = go ? ns : 0u;
+    const uint32_t n_it = wv.max_u32(my_ns);
+    s.rd.start(wv, s.pos);
+    regular_phase<W, 0, OUT_NONE, true>(wv, cfg, bits, s, size, my_ns, n_it, 0u, 0u, chan_bits, 0, 0u, 0u, 0u, 0u, 0u);
+    if (go) {
+        pos = s.pos;
+        err = s.err;
     }
 }
 
@@ -587,8 +675,8 @@ ALAC_DEV int32_t decode_regular(W& wv, const DevCfg& cfg, uint32_t key, bool liv
     s.zrem = 0;
     s.pb = (cfg.pb * ((hu >> 5) & 7u)) / 4u; /* decoder.go:299 */
     s.rd.start(wv, live ? s.pos : 0u);
-    if (cpe) regular_phase_na<W, false, true>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
-    else regular_phase_na<W, true, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
+    if (cpe) regular_phase_na<W, OUT_UTILE, true>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u, 0u);
+    else regular_phase_na<W, OUT_MONO, true>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb, 0u);
     uint32_t err_chan = 0;
     /* ---- V ---- */
     if (cpe) {
@@ -600,7 +688,7 @@ ALAC_DEV int32_t decode_regular(W& wv, const DevCfg& cfg, uint32_t key, bool liv
         s.zrem = 0;
         s.pb = (cfg.pb * ((hv >> 5) & 7u)) / 4u;
         s.rd.start(wv, (live && s.err == 0) ? s.pos : 0u);
-        regular_phase_na<W, true, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+        regular_phase_na<W, OUT_STEREO, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb, 0u);
         if (err_u == 0 && s.err != 0) err_chan = 1;
     }
     if (!live) return 0;

@@ -1,0 +1,127 @@
+/*
+ * alac_split.h — the split pipeline for packets with more than two channels (BASELINE config d).
+ *
+ * A packet of E elements is a serial chain E times as long as a stereo one if a single lane walks it
+ * (decoder.go:142-203: element k+1 starts where the entropy stream of element k ends, and nothing in the
+ * bitstream says where that is). The split pipeline cuts the chain:
+ *
+ *   1. scan     decode_wave<..., SCAN> (alac_wave.h): one lane per packet walks the packet with the lean
+ *               Golomb loop only (no predictor, no PCM), records where every channel's entropy stream starts
+ *               (ChanDesc) and settles the packet's status and frame count (PktDesc) — every error the
+ *               reference can raise is raised here, in stream order;
+ *   2. decode   decode_channel_task: one lane per (packet, channel), waves sorted by predictor order, the lean
+ *               phase of alac_regular.h writing int32 samples to the task's row through the LDS stager
+ *               (coalesced 128-B lines);
+ *   3. interleave  interleave_frame: one thread per (packet, frame): unmix pairs (matrix.go:40-41), shift-byte
+ *               merge (matrix.go:129-132), escape elements straight from the bitstream (decoder.go:326-345,
+ *               507-535), PCM bytes in frame order (coalesced both ways), zero fill of unwritten slots.
+ *
+ * Packets whose orders have no lean instantiation (17..30) take decode_wave whole (ROUTE_LEGACY).
+ */
+#ifndef ALAC_SPLIT_H
+#define ALAC_SPLIT_H
+
+#include "alac_regular.h"
+
+namespace alac {
+
+/* sort key of a channel task: order | wide << 5 (wide: chanBits > 23, plain 32-bit arithmetic) */
+ALAC_DEV bool chan_is_narrow(const DevCfg& cfg, uint32_t chan_bits) {
+    return chan_bits <= 23u && cfg.frame_length <= 65536u;
+}
+ALAC_DEV uint32_t chan_task_key(const DevCfg& cfg, const ChanDesc& d) {
+    const uint32_t na = (d.info >> CD_NA_SHIFT) & 31u;
+    const uint32_t chan_bits = (d.info >> CD_CHANBITS_SHIFT) & 63u;
+    return na | (chan_is_narrow(cfg, chan_bits) ? 0u : 32u);
+}
+constexpr uint32_t NUM_TASK_KEYS = 64;
+constexpr uint32_t TASK_NONE = 0xffffu;
+
+/* samples of one channel: every lane of the wave holds a task with the same key (live = false: no task) */
+template <class W>
+ALAC_DEV void decode_channel_task(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
+                                  const ChanDesc& d, int32_t* row) {
+    const Bits bits{pkt, size};
+    const uint32_t na = key & 31u;
+    const bool narrow = (key & 32u) == 0;
+    RegLane<W> s;
+    s.rd.init(pkt, size);
+    s.err = 0;
+    s.max_pos = size * 8u;
+    const uint32_t h = bits.get(d.hdr_pos, 16);
+    const uint32_t mode = live ? (h >> 12) : 0u;
+    const uint32_t den_shift = (h >> 8) & 0xfu;
+    s.pb = (cfg.pb * ((h >> 5) & 7u)) / 4u; /* decoder.go:299 */
+    s.mean = cfg.mb;
+    s.zmode = 0;
+    s.zrem = 0;
+    s.pos = live ? d.ent_pos : 0u;
+    const uint32_t ns = live ? d.ns : 0u;
+    const uint32_t chan_bits = live ? ((d.info >> CD_CHANBITS_SHIFT) & 63u) : 16u;
+    const uint32_t n_it = wv.max_u32(ns);
+    if (live) wv.st_begin(reinterpret_cast<uint8_t*>(row));
+    s.rd.start(wv, s.pos);
+    if (narrow)
+        regular_phase_na<W, OUT_RAW, true>(wv, na, cfg, bits, s, size, ns, n_it, d.hdr_pos, den_shift, chan_bits, 0, 0u, 0u,
+                                          0u, mode);
+    else
+        regular_phase_na<W, OUT_RAW, false>(wv, na, cfg, bits, s, size, ns, n_it, d.hdr_pos, den_shift, chan_bits, 0, 0u,
+                                           0u, 0u, mode);
+    if (live) (void)wv.st_finish();
+}
+
+/* PCM of frame i of one split packet. rows: the packet's sample rows, row r at rows + r*row_stride. */
+ALAC_DEV void interleave_frame(const DevCfg& cfg, const uint8_t* pkt, uint32_t size, const PktDesc& pd,
+                               const ChanDesc* cd, const int32_t* rows, size_t row_stride, uint32_t i, uint8_t* out) {
+    const Bits bits{pkt, size};
+    const uint32_t num_chan = cfg.num_channels, bps = cfg.bps, depth = cfg.bit_depth;
+    uint8_t* frame = out + (size_t)i * num_chan * bps;
+    for (uint32_t slot = 0; slot < pd.nslots; ++slot) {
+        const ChanDesc d = cd[slot];
+        if (!(d.info & CD_VALID) || (d.info & CD_SECOND) || i >= d.ns) continue;
+        const bool cpe = (d.info & CD_CPE) != 0, escape = (d.info & CD_ESCAPE) != 0;
+        const uint32_t nch_e = cpe ? 2u : 1u;
+        const uint32_t chan_bits = (d.info >> CD_CHANBITS_SHIFT) & 63u;
+        const uint32_t out_chan = (d.info >> CD_OUTCHAN_SHIFT) & 7u;
+        const uint32_t sb = (d.info >> CD_SB_SHIFT) & 31u;
+        int32_t a, b = 0;
+        if (escape) { /* decodeSCEEscape / decodeCPEEscape, decoder.go:326-345 / 507-535 */
+            const uint32_t cs = 32u - chan_bits;
+            a = sext_cs((int32_t)bits.get(d.hdr_pos + (i * nch_e) * chan_bits, chan_bits), cs);
+            if (cpe) b = sext_cs((int32_t)bits.get(d.hdr_pos + (i * nch_e + 1u) * chan_bits, chan_bits), cs);
+        } else {
+            a = rows[(size_t)slot * row_stride + i];
+            if (cpe) b = rows[(size_t)(slot + 1u) * row_stride + i];
+        }
+        int32_t l = a, r = 0;
+        if (cpe) {
+            const int32_t mix_res = (int32_t)(int8_t)(d.mix & 0xff);
+            const uint32_t mix_sh = ((uint32_t)d.mix >> 8) & 31u;
+            if (mix_res != 0) { /* matrix.go:40-41 */
+                l = a + b - ((mix_res * b) >> mix_sh);
+                r = l - b;
+            } else {
+                r = b;
+            }
+        }
+        if (depth == 20) { /* matrix.go:77-78, 237 */
+            l = (int32_t)((uint32_t)l << 4);
+            r = (int32_t)((uint32_t)r << 4);
+        }
+        if (sb) { /* matrix.go:129-132, 266-268 */
+            const uint32_t sp = d.shift_pos + i * nch_e * sb;
+            l = (int32_t)((uint32_t)l << sb) | (int32_t)bits.get(sp, sb);
+            if (cpe) r = (int32_t)((uint32_t)r << sb) | (int32_t)bits.get(sp + sb, sb);
+        }
+        uint8_t* dst = frame + out_chan * bps;
+        store_le(dst, l, bps);
+        if (cpe) store_le(dst + bps, r, bps);
+    }
+    /* DecodePacket hands back output[:n] of a zeroed buffer (decoder.go:120,127) */
+    for (uint32_t sidx = 0; sidx < num_chan; ++sidx)
+        if (i >= pd.written[sidx])
+            for (uint32_t k = 0; k < bps; ++k) frame[sidx * bps + k] = 0;
+}
+
+} /* namespace alac */
+#endif

@@ -184,6 +184,38 @@ ALAC_DEV uint32_t classify_packet(const uint8_t* pkt, uint32_t size) {
     return classify_orders(nu, nv);
 }
 
+/* ---- descriptors of the split pipeline (alac_split.h): written by the scan pass, one per bitstream channel ---- */
+struct ChanDesc {
+    uint32_t hdr_pos;   /* compressed: bit position of the channel's predictor header; escape: first raw sample */
+    uint32_t ent_pos;   /* compressed: first bit of the channel's entropy stream */
+    uint32_t ns;        /* numSamples of the element */
+    uint32_t shift_pos; /* first bit of the element's shift block */
+    uint32_t info;      /* CD_* fields below */
+    int32_t mix;        /* mixRes (low 8 bits, signed) | mixBits clamped to 31 << 8 */
+    uint32_t pad0, pad1;
+};
+enum {
+    CD_VALID = 1u << 0, CD_ESCAPE = 1u << 1, CD_CPE = 1u << 2, CD_SECOND = 1u << 3,
+    CD_CHANBITS_SHIFT = 4,  /* 6 bits: 0..33 */
+    CD_OUTCHAN_SHIFT = 10,  /* 3 bits: output slot of THIS channel */
+    CD_SB_SHIFT = 13,       /* 5 bits: shift bits merged into the PCM (0, 8, 16) */
+    CD_NA_SHIFT = 18,       /* 5 bits */
+    CD_MODE = 1u << 23,
+};
+struct PktDesc {
+    int32_t status;
+    uint32_t frames;
+    uint32_t nslots;     /* bitstream channels described */
+    uint32_t route;      /* ROUTE_* */
+    uint32_t written[8]; /* frames written per output slot */
+};
+enum { ROUTE_NONE = 0, ROUTE_SPLIT = 1, ROUTE_LEGACY = 2 };
+
+/* Golomb-only pass over one channel (defined in alac_regular.h): advances pos to the end of the entropy stream */
+template <class W>
+ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const Bits& bits, const uint8_t* pkt, uint32_t size, bool go,
+                           uint32_t& pos, uint32_t ns, uint32_t pb_local, uint32_t chan_bits, int32_t& err);
+
 /* ------------------------------------------------------------------------------------------------------
  * decode_wave<W, NA, WRAP>: every lane of the wave calls this with its own packet (live = false for lanes
  * without one). W is the wave policy:
@@ -198,9 +230,13 @@ ALAC_DEV uint32_t classify_packet(const uint8_t* pkt, uint32_t size) {
  * NA = predictor taps held in registers; WRAP = compile the per-lane int16 coefficient wrap.
  * Returns the status word; *frames_out = numSamples of the last element (decoder.go:206).
  * ------------------------------------------------------------------------------------------------------ */
-template <class W, int NA, bool WRAP>
+template <class W, int NA, bool WRAP, bool SCAN = false>
 ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t* pkt, uint32_t size, uint8_t* out,
-                             uint32_t* frames_out) {
+                             uint32_t* frames_out, ChanDesc* cd = nullptr, PktDesc* pd = nullptr) {
+    /* SCAN: walk the packet exactly like a decode (same errors in the same order) but only find where every
+     * channel's entropy stream starts and ends (scan_channel), describe the channels in cd[0..7] and the packet
+     * in *pd; no prediction, no PCM. */
+    bool legacy = false;
     const Bits bits{pkt, size};
     const uint32_t num_chan = cfg.num_channels;
     const uint32_t bps = cfg.bps;
@@ -361,7 +397,7 @@ ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t*
             has = true;
         }
         /* PCM of an element that covers the whole frame is one contiguous stream: stage it through LDS */
-        staged = has && cfg.aligned16 != 0 && nch_e == num_chan;
+        staged = !SCAN && has && cfg.aligned16 != 0 && nch_e == num_chan;
         if (staged) wv.st_begin(out);
 
         /* ================= phase B (wave-uniform): channels of the element, U then V ====================== */
@@ -386,7 +422,9 @@ ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t*
                 pb_local = (cfg.pb * ((h >> 5) & 7u)) / 4u; /* decoder.go:299 */
                 na = h & 0x1fu;
                 fast = na == 0 || na == 31 || (na <= (uint32_t)NA && (WRAP || !order_wraps16(na)));
-                if (fast) {
+                if (SCAN) {
+                    legacy = legacy || (na > 16 && na != 31); /* no lean instantiation for orders 17..30 */
+                } else if (fast) {
 #pragma unroll
                     for (int j = 0; j < NA; ++j)
                         if ((uint32_t)j < na) coef[j] = (int32_t)(int16_t)bits.get(hdr_pos + 16u + 16u * (uint32_t)j, 16);
@@ -400,6 +438,19 @@ ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t*
                     err_chan = c;
                 }
             }
+            if (SCAN && part && cd) {
+                ChanDesc d;
+                d.hdr_pos = escape ? data_pos : hdr_pos - (16u + 16u * na);
+                d.ent_pos = pos;
+                d.ns = ns;
+                d.shift_pos = shift_pos;
+                d.info = CD_VALID | (escape ? CD_ESCAPE : 0u) | (cpe ? CD_CPE : 0u) | (c ? CD_SECOND : 0u) |
+                         (chan_bits << CD_CHANBITS_SHIFT) | ((out_chan + c) << CD_OUTCHAN_SHIFT) |
+                         ((use_shift ? shift_bits : 0u) << CD_SB_SHIFT) | (na << CD_NA_SHIFT) | (mode ? CD_MODE : 0u);
+                d.mix = (int32_t)((uint32_t)(mix_res & 0xff) | (mix_sh << 8));
+                d.pad0 = d.pad1 = 0;
+                cd[chan_idx + c] = d;
+            }
             const bool run = part && err == 0;
             const bool wrap16 = WRAP && order_wraps16(na);
             const int32_t den_half = den_shift ? (int32_t)(1u << (den_shift - 1u)) : 0;
@@ -412,9 +463,18 @@ ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t*
 #pragma unroll
             for (int j = 0; j <= NA; ++j) hist[j] = 0;
             int32_t dprev = 0; /* delta pre-pass state (mode != 0) */
-            if (run && !escape && ns != 0) rd.seek(pos);
+            if (SCAN) {
+                int32_t e2 = 0;
+                scan_channel<W>(wv, cfg, bits, pkt, size, run && !escape && ns != 0, pos, ns, pb_local, chan_bits, e2);
+                if (run && e2) {
+                    err = e2;
+                    err_chan = c;
+                }
+            } else if (run && !escape && ns != 0) {
+                rd.seek(pos);
+            }
 
-            const uint32_t n_it = wv.max_u32(run ? ns : 0u);
+            const uint32_t n_it = SCAN ? 0u : wv.max_u32(run ? ns : 0u);
             for (uint32_t i = 0; i < n_it; ++i) {
                 const bool on = run && i < ns && err == 0;
                 if (on) {
@@ -700,7 +760,25 @@ ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t*
         /* a Go panic carries no wrapping context: report the bare code */
         if (ALACGPU_STATUS_CODE(st) == ST_MALFORMED) st = ST_MALFORMED;
         *frames_out = 0;
+        if (SCAN && pd) {
+            pd->status = st;
+            pd->frames = 0;
+            pd->nslots = 0;
+            pd->route = ROUTE_NONE;
+        }
         return st;
+    }
+    if (SCAN) {
+        if (pd) {
+            pd->status = 0;
+            pd->frames = num_samples;
+            pd->nslots = chan_idx;
+            pd->route = legacy ? ROUTE_LEGACY : ROUTE_SPLIT;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) pd->written[k] = written[k];
+        }
+        *frames_out = num_samples;
+        return 0;
     }
     /* DecodePacket hands back output[:n] of a zeroed frame buffer (decoder.go:120,127): slots no element
      * wrote, or wrote for fewer frames than the last element, read as zero */

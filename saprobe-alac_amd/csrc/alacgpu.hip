@@ -46,6 +46,7 @@ typedef uint32_t alac_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
     } while (0)
 #include "alac_wave.h"
 #include "alac_regular.h"
+#include "alac_split.h"
 
 namespace {
 
@@ -62,6 +63,8 @@ constexpr uint32_t kRingStride = 36; /* 32 ring dwords + 4: rows stay 16-byte al
 /* sort keys: 0..1023 regular packets (numU*32 + numV, alac_regular.h); 1024+c irregular packets of
  * predictor class c (alac_wave.h). A wave holds packets of ONE key. */
 constexpr uint32_t kKeys = 1024 + alac::NUM_CLASSES;
+constexpr uint32_t kKeyLegacy = 1024; /* decode_wave */
+constexpr uint32_t kKeyScan = 1025;   /* decode_wave<SCAN> + split pipeline */
 struct Plan {
     uint32_t count[kKeys];     /* packets per key */
     uint32_t pkt_start[kKeys]; /* first index in perm[] */
@@ -169,7 +172,9 @@ alac_classify(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t
     if (i < n) {
         const uint8_t* p = blob + offsets[i];
         uint32_t key = alac::classify_regular(cfg, p, sizes[i]);
-        if (key == alac::KEY_IRREGULAR) key = 1024u + alac::classify_packet(p, sizes[i]);
+        /* not regular: more than two channels (and a usable KB) -> split pipeline, starting with the scan;
+         * everything else -> the whole-packet decoder */
+        if (key == alac::KEY_IRREGULAR) key = (cfg.num_channels > 2 && cfg.kb != 0) ? kKeyScan : kKeyLegacy;
         keys[i] = (uint16_t)key;
         atomicAdd(&hist[key], 1u);
     }
@@ -220,13 +225,13 @@ alac_scatter(const uint16_t* __restrict__ keys, uint32_t n, Plan* plan, uint32_t
     uint32_t key = 0, local = 0;
     if (i < n) {
         key = keys[i];
-        local = atomicAdd(&hist[key], 1u);
+        if (key != alac::TASK_NONE) local = atomicAdd(&hist[key], 1u);
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x)
         if (hist[k]) base[k] = plan->pkt_start[k] + atomicAdd(&plan->cursor[k], hist[k]);
     __syncthreads();
-    if (i < n) perm[base[key] + local] = i;
+    if (i < n && key != alac::TASK_NONE) perm[base[key] + local] = i;
 }
 
 __global__ void __launch_bounds__(kWave)
@@ -234,7 +239,7 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
             const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
             uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
             int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g,
-            uint32_t ppw) {
+            uint32_t ppw, alac::ChanDesc* __restrict__ cd, alac::PktDesc* __restrict__ pd) {
 
     const uint32_t b = blockIdx.x;
     if (b >= plan->total_waves) return;
@@ -269,14 +274,130 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
     if (ukey < 1024u) {
         st = alac::decode_regular<GpuWave>(wv, cfg, ukey, live, p, size, o, &frames);
+    } else if (ukey == kKeyScan) {
+        /* split pipeline, step 1: status, frame count and channel descriptors; PCM comes from alac_interleave */
+        st = alac::decode_wave<GpuWave, 16, true, true>(wv, cfg, live, p, size, o, &frames, cd + (size_t)pkt * 8u,
+                                                        pd + pkt);
     } else {
-        switch (ukey - 1024u) {
-            case alac::CLASS_NA4: st = alac::decode_wave<GpuWave, 4, false>(wv, cfg, live, p, size, o, &frames); break;
-            case alac::CLASS_NA6: st = alac::decode_wave<GpuWave, 6, false>(wv, cfg, live, p, size, o, &frames); break;
-            case alac::CLASS_NA8: st = alac::decode_wave<GpuWave, 8, false>(wv, cfg, live, p, size, o, &frames); break;
-            default: st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, o, &frames); break;
-        }
+        st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, o, &frames);
     }
+    if (live) {
+        frames_out[pkt] = frames;
+        status[pkt] = st;
+    }
+}
+
+/* ---- split pipeline (alac_split.h) -------------------------------------------------------------------- */
+/* one thread per (packet, bitstream channel): sort key of the channel task, or TASK_NONE */
+__global__ void __launch_bounds__(256)
+alac_task_classify(alac::DevCfg cfg, const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd,
+                   const uint16_t* __restrict__ pkt_keys, uint32_t n_slots, uint16_t* __restrict__ keys, Plan* plan) {
+    __shared__ uint32_t hist[alac::NUM_TASK_KEYS];
+    if (threadIdx.x < alac::NUM_TASK_KEYS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_slots) {
+        const uint32_t pkt = t >> 3, slot = t & 7u;
+        uint32_t key = alac::TASK_NONE;
+        if (pkt_keys[pkt] == kKeyScan) {
+            const alac::PktDesc q = pd[pkt];
+            if (q.status == 0 && q.route == alac::ROUTE_SPLIT && slot < q.nslots) {
+                const alac::ChanDesc d = cd[t];
+                if ((d.info & alac::CD_VALID) && !(d.info & alac::CD_ESCAPE)) key = alac::chan_task_key(cfg, d);
+            }
+        }
+        keys[t] = (uint16_t)key;
+        if (key != alac::TASK_NONE) atomicAdd(&hist[key], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < alac::NUM_TASK_KEYS && hist[threadIdx.x]) atomicAdd(&plan->count[threadIdx.x], hist[threadIdx.x]);
+}
+
+/* one wavefront per 64 channel tasks with the same key: int32 samples of the channel into its row */
+__global__ void __launch_bounds__(kWave)
+alac_chan_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                 const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+                 const alac::ChanDesc* __restrict__ cd, int32_t* __restrict__ rows, uint64_t row_stride, uint32_t ppw) {
+    const uint32_t b = blockIdx.x;
+    if (b >= plan->total_waves) return;
+    uint32_t e = 0;
+    for (uint32_t t = 1; t < plan->nk; ++t)
+        if (plan->list_wave0[t] <= b) e = t;
+    const uint32_t key = plan->list_key[e];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t idx = (b - plan->list_wave0[e]) * ppw + lane;
+    const bool live = lane < ppw && idx < plan->count[key];
+    const uint32_t t = live ? perm[plan->pkt_start[key] + idx] : 0u;
+    const uint32_t pkt = t >> 3, slot = t & 7u;
+
+    GpuWave wv;
+    wv.u_stride = 0;
+    wv.u_tile = nullptr;
+    wv.g_tile = nullptr;
+    wv.ppw = ppw;
+    wv.my_out = nullptr;
+    wv.lane = lane;
+    wv.wcnt = wv.flushed = 0;
+
+    const uint8_t* p = blob + (live ? offsets[pkt] : offsets[0]);
+    const uint32_t size = live ? sizes[pkt] : 0u;
+    alac::ChanDesc d = cd[t];
+    if (!live) d.hdr_pos = d.ent_pos = d.ns = 0;
+    int32_t* row = rows + ((size_t)pkt * cfg.num_channels + slot) * row_stride;
+    alac::decode_channel_task<GpuWave>(wv, cfg, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), live, p, size, d, row);
+}
+
+/* one thread per (packet, frame) of the split packets: PCM in frame order */
+__global__ void __launch_bounds__(256)
+alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+                const uint32_t* __restrict__ sizes, const uint16_t* __restrict__ pkt_keys,
+                const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd, const int32_t* __restrict__ rows,
+                uint64_t row_stride, uint8_t* __restrict__ out, uint64_t out_stride, uint32_t blocks_per_pkt) {
+    const uint32_t pkt = blockIdx.x / blocks_per_pkt;
+    if (pkt_keys[pkt] != kKeyScan) return;
+    const alac::PktDesc q = pd[pkt];
+    if (q.status != 0 || q.route != alac::ROUTE_SPLIT) return;
+    const uint32_t f = (blockIdx.x % blocks_per_pkt) * blockDim.x + threadIdx.x;
+    if (f >= q.frames) return;
+    alac::interleave_frame(cfg, blob + offsets[pkt], sizes[pkt], q, cd + (size_t)pkt * 8u,
+                           rows + (size_t)pkt * cfg.num_channels * row_stride, (size_t)row_stride, f,
+                           out + (size_t)pkt * out_stride);
+}
+
+/* packets the scan routed to the whole-packet decoder (orders 17..30): same wave mapping as alac_decode */
+__global__ void __launch_bounds__(kWave)
+alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+            const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+            const alac::PktDesc* __restrict__ pd, uint8_t* __restrict__ out, uint64_t out_stride,
+            uint32_t* __restrict__ frames_out, int32_t* __restrict__ status, int32_t* __restrict__ scratch_u,
+            int32_t* __restrict__ scratch_g, uint32_t ppw) {
+    const uint32_t b = blockIdx.x;
+    if (b >= plan->total_waves) return;
+    uint32_t e = 0;
+    for (uint32_t t = 1; t < plan->nk; ++t)
+        if (plan->list_wave0[t] <= b) e = t;
+    const uint32_t key = plan->list_key[e];
+    if (key != kKeyScan) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t idx = (b - plan->list_wave0[e]) * ppw + lane;
+    const bool in_wave = lane < ppw && idx < plan->count[key];
+    const uint32_t pkt = in_wave ? perm[plan->pkt_start[key] + idx] : 0u;
+    const bool live = in_wave && pd[pkt].status == 0 && pd[pkt].route == alac::ROUTE_LEGACY;
+    if (__ballot(live) == 0ull) return;
+
+    GpuWave wv;
+    const size_t tile_cells = (size_t)cfg.frame_length * ppw + kWave;
+    wv.u_stride = lane < ppw ? ppw : 0u;
+    wv.u_tile = scratch_u + (size_t)b * tile_cells + (lane < ppw ? lane : (size_t)cfg.frame_length * ppw + lane);
+    wv.g_tile = scratch_g + (size_t)b * kFallbackSlots * ppw + lane;
+    wv.ppw = ppw;
+    wv.my_out = nullptr;
+    wv.lane = lane;
+    wv.wcnt = wv.flushed = 0;
+    const uint8_t* p = blob + (live ? offsets[pkt] : offsets[0]);
+    const uint32_t size = live ? sizes[pkt] : 0u;
+    uint32_t frames = 0;
+    const int32_t st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, out + (size_t)pkt * out_stride, &frames);
     if (live) {
         frames_out[pkt] = frames;
         status[pkt] = st;
@@ -362,6 +483,7 @@ struct alacgpu_decoder {
     hipEvent_t ev_start[kTimingSlots], ev_stop[kTimingSlots]; /* ring of per-launch event pairs */
     uint64_t launches;                                       /* since the last timing reset */
     DevBuf scratch_u, scratch_g, plan, cls, perm;            /* kernel workspace */
+    DevBuf cd, pd, plan2, keys2, perm2, rows;                /* split pipeline (more than two channels) */
     DevBuf d_blob, d_offsets, d_sizes, d_out, d_frames, d_status; /* host-entry staging */
     HostBuf h_blob, h_meta;
 };
@@ -385,6 +507,8 @@ uint32_t pick_ppw(size_t n) {
     return ppw;
 }
 
+size_t row_stride_of(uint32_t frame_length) { return ((size_t)frame_length + 3u) & ~(size_t)3u; } /* 16-byte rows */
+
 int reserve_workspace(alacgpu_decoder* dec, size_t n, uint32_t ppw) {
     const size_t waves = max_waves(n, ppw);
     int rc;
@@ -393,6 +517,16 @@ int reserve_workspace(alacgpu_decoder* dec, size_t n, uint32_t ppw) {
     if ((rc = dec->plan.ensure(sizeof(Plan)))) return rc;
     if ((rc = dec->cls.ensure((n ? n : 1) * sizeof(uint16_t)))) return rc;
     if ((rc = dec->perm.ensure((n ? n : 1) * sizeof(uint32_t)))) return rc;
+    if (dec->cfg.num_channels > 2) {
+        const size_t ns = (n ? n : 1) * 8;
+        if ((rc = dec->cd.ensure(ns * sizeof(alac::ChanDesc)))) return rc;
+        if ((rc = dec->pd.ensure((n ? n : 1) * sizeof(alac::PktDesc)))) return rc;
+        if ((rc = dec->plan2.ensure(sizeof(Plan)))) return rc;
+        if ((rc = dec->keys2.ensure(ns * sizeof(uint16_t)))) return rc;
+        if ((rc = dec->perm2.ensure(ns * sizeof(uint32_t)))) return rc;
+        if ((rc = dec->rows.ensure((n ? n : 1) * dec->cfg.num_channels * row_stride_of(dec->cfg.frame_length) * sizeof(int32_t))))
+            return rc;
+    }
     return ALACGPU_E_OK;
 }
 
@@ -420,8 +554,35 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
     HIP_TRY(hipEventRecord(dec->ev_start[slot], dec->stream));
     hipLaunchKernelGGL(alac_decode, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, d_offsets,
                        d_sizes, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride, d_frames,
-                       d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw);
+                       d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw, (alac::ChanDesc*)dec->cd.p,
+                       (alac::PktDesc*)dec->pd.p);
     HIP_TRY(hipGetLastError());
+    if (dec->cfg.num_channels > 2) {
+        /* split pipeline: the scan ran inside alac_decode; now one lane per channel, then the interleave */
+        Plan* plan2 = (Plan*)dec->plan2.p;
+        const size_t n_slots = n * 8;
+        const uint32_t nb2 = (uint32_t)((n_slots + 255) / 256);
+        const uint32_t ppw2 = pick_ppw(n * dec->cfg.num_channels);
+        const uint64_t rs = row_stride_of(dec->cfg.frame_length);
+        const uint32_t bpp = (dec->cfg.frame_length + 255u) / 256u;
+        HIP_TRY(hipMemsetAsync(plan2, 0, sizeof(Plan), dec->stream));
+        hipLaunchKernelGGL(alac_task_classify, dim3(nb2), dim3(256), 0, dec->stream, c, (const alac::ChanDesc*)dec->cd.p,
+                           (const alac::PktDesc*)dec->pd.p, (const uint16_t*)dec->cls.p, (uint32_t)n_slots,
+                           (uint16_t*)dec->keys2.p, plan2);
+        hipLaunchKernelGGL(alac_plan, dim3(1), dim3(256), 0, dec->stream, plan2, ppw2);
+        hipLaunchKernelGGL(alac_scatter, dim3(nb2), dim3(256), 0, dec->stream, (const uint16_t*)dec->keys2.p,
+                           (uint32_t)n_slots, plan2, (uint32_t*)dec->perm2.p);
+        hipLaunchKernelGGL(alac_chan_decode, dim3((uint32_t)max_waves(n_slots, ppw2)), dim3(kWave), 0, dec->stream, c, d_blob,
+                           d_offsets, d_sizes, (const uint32_t*)dec->perm2.p, (const Plan*)plan2,
+                           (const alac::ChanDesc*)dec->cd.p, (int32_t*)dec->rows.p, rs, ppw2);
+        hipLaunchKernelGGL(alac_interleave, dim3((uint32_t)(n * bpp)), dim3(256), 0, dec->stream, c, d_blob, d_offsets, d_sizes,
+                           (const uint16_t*)dec->cls.p, (const alac::ChanDesc*)dec->cd.p, (const alac::PktDesc*)dec->pd.p,
+                           (const int32_t*)dec->rows.p, rs, d_out, (uint64_t)out_stride, bpp);
+        hipLaunchKernelGGL(alac_legacy, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, d_offsets,
+                           d_sizes, (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::PktDesc*)dec->pd.p, d_out,
+                           (uint64_t)out_stride, d_frames, d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(dec->ev_stop[slot], dec->stream));
     dec->launches++;
     return ALACGPU_E_OK;
@@ -485,6 +646,12 @@ void alacgpu_destroy(alacgpu_decoder* d) {
     d->plan.release();
     d->cls.release();
     d->perm.release();
+    d->cd.release();
+    d->pd.release();
+    d->plan2.release();
+    d->keys2.release();
+    d->perm2.release();
+    d->rows.release();
     d->d_blob.release();
     d->d_offsets.release();
     d->d_sizes.release();

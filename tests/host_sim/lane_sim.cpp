@@ -14,6 +14,7 @@
 #define ALAC_DEV inline
 #include "../../saprobe-alac_amd/csrc/alac_wave.h"
 #include "../../saprobe-alac_amd/csrc/alac_regular.h"
+#include "../../saprobe-alac_amd/csrc/alac_split.h"
 
 namespace {
 
@@ -56,8 +57,10 @@ struct HostWave {
 }  // namespace
 
 /* variant: 0..3 = force that class's generic variant (any class must decode any packet correctly);
- *          -1   = pick like the GPU pre-pass does (lean decoder for regular packets). classes_out (may be null)
- *                 gets the sort key. */
+ *          -1   = route like alacgpu.hip does (lean decoder for regular packets, split pipeline for > 2 channels,
+ *                 whole-packet decoder otherwise);
+ *          -2   = split pipeline for every non-regular packet, whatever the channel count.
+ * classes_out (may be null) gets the sort key / route. */
 extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* blob, const uint64_t* offsets,
                                      const uint32_t* sizes, size_t n, uint8_t* out, size_t out_stride,
                                      uint32_t* frames_out, int32_t* status, int poison, int variant,
@@ -91,8 +94,30 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
                 continue;
             }
         }
-        const uint32_t cls = variant >= 0 ? (uint32_t)variant : alac::classify_packet(p, sizes[i]);
-        if (classes_out) classes_out[i] = 1024u + cls;
+        if ((variant == -1 && cfg->num_channels > 2 && dc.kb != 0) || (variant == -2 && dc.kb != 0)) {
+            /* split pipeline, as alacgpu.hip runs it: scan -> one lean phase per channel -> interleave */
+            alac::ChanDesc cd[8];
+            memset(cd, 0, sizeof(cd));
+            alac::PktDesc pd{};
+            status[i] = alac::decode_wave<HostWave, 16, true, true>(wv, dc, true, p, sizes[i], o, &frames_out[i], cd, &pd);
+            if (classes_out) classes_out[i] = 2048u + pd.route;
+            if (status[i] != 0) continue;
+            if (pd.route == alac::ROUTE_SPLIT) {
+                const size_t rs = (cfg->frame_length + 3u) & ~3u;
+                std::vector<int32_t> rows(rs * 8, 0x5a5a5a5a);
+                for (uint32_t sl = 0; sl < pd.nslots; ++sl) {
+                    if (!(cd[sl].info & alac::CD_VALID) || (cd[sl].info & alac::CD_ESCAPE)) continue;
+                    alac::decode_channel_task<HostWave>(wv, dc, alac::chan_task_key(dc, cd[sl]), true, p, sizes[i], cd[sl],
+                                                        rows.data() + rs * sl);
+                }
+                for (uint32_t f = 0; f < pd.frames; ++f)
+                    alac::interleave_frame(dc, p, sizes[i], pd, cd, rows.data(), rs, f, o);
+                continue;
+            }
+            /* ROUTE_LEGACY: fall through to the whole-packet decoder */
+        }
+        const uint32_t cls = variant >= 0 ? (uint32_t)variant : 3u;
+        if (classes_out && variant >= 0) classes_out[i] = 1024u + cls;
         switch (cls) {
             case alac::CLASS_NA4: status[i] = alac::decode_wave<HostWave, 4, false>(wv, dc, true, p, sizes[i], o, &frames_out[i]); break;
             case alac::CLASS_NA6: status[i] = alac::decode_wave<HostWave, 6, false>(wv, dc, true, p, sizes[i], o, &frames_out[i]); break;
