@@ -423,7 +423,9 @@ ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t*
                 na = h & 0x1fu;
                 fast = na == 0 || na == 31 || (na <= (uint32_t)NA && (WRAP || !order_wraps16(na)));
                 if (SCAN) {
-                    legacy = legacy || (na > 16 && na != 31); /* no lean instantiation for orders 17..30 */
+                    /* no lean instantiation for orders 17..30; with one or two channels only escape elements take
+                     * the split pipeline (no sample rows are kept for them), compressed ones go to decode_wave */
+                    legacy = legacy || (na > 16 && na != 31) || num_chan <= 2;
                 } else if (fast) {
 #pragma unroll
                     for (int j = 0; j < NA; ++j)

@@ -172,9 +172,9 @@ alac_classify(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t
     if (i < n) {
         const uint8_t* p = blob + offsets[i];
         uint32_t key = alac::classify_regular(cfg, p, sizes[i]);
-        /* not regular: more than two channels (and a usable KB) -> split pipeline, starting with the scan;
-         * everything else -> the whole-packet decoder */
-        if (key == alac::KEY_IRREGULAR) key = (cfg.num_channels > 2 && cfg.kb != 0) ? kKeyScan : kKeyLegacy;
+        /* not regular: scan first (with a usable KB). More than two channels: split pipeline. One or two: escape
+         * elements are unpacked by alac_interleave, anything else is handed to the whole-packet decoder. */
+        if (key == alac::KEY_IRREGULAR) key = cfg.kb != 0 ? kKeyScan : kKeyLegacy;
         keys[i] = (uint16_t)key;
         atomicAdd(&hist[key], 1u);
     }
@@ -274,10 +274,12 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
     if (ukey < 1024u) {
         st = alac::decode_regular<GpuWave>(wv, cfg, ukey, live, p, size, o, &frames);
+#ifndef ALAC_EXP_NO_SCAN
     } else if (ukey == kKeyScan) {
         /* split pipeline, step 1: status, frame count and channel descriptors; PCM comes from alac_interleave */
         st = alac::decode_wave<GpuWave, 16, true, true>(wv, cfg, live, p, size, o, &frames, cd + (size_t)pkt * 8u,
                                                         pd + pkt);
+#endif
     } else {
         st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, o, &frames);
     }
@@ -347,21 +349,26 @@ alac_chan_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint6
     alac::decode_channel_task<GpuWave>(wv, cfg, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), live, p, size, d, row);
 }
 
-/* one thread per (packet, frame) of the split packets: PCM in frame order */
+/* one thread per (packet, frame) of the split packets: PCM in frame order. Blocks stride over the scanned
+ * packets (the tail of the permutation that belongs to kKeyScan) x 256-frame slices. */
 __global__ void __launch_bounds__(256)
 alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
-                const uint32_t* __restrict__ sizes, const uint16_t* __restrict__ pkt_keys,
+                const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
                 const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd, const int32_t* __restrict__ rows,
                 uint64_t row_stride, uint8_t* __restrict__ out, uint64_t out_stride, uint32_t blocks_per_pkt) {
-    const uint32_t pkt = blockIdx.x / blocks_per_pkt;
-    if (pkt_keys[pkt] != kKeyScan) return;
-    const alac::PktDesc q = pd[pkt];
-    if (q.status != 0 || q.route != alac::ROUTE_SPLIT) return;
-    const uint32_t f = (blockIdx.x % blocks_per_pkt) * blockDim.x + threadIdx.x;
-    if (f >= q.frames) return;
-    alac::interleave_frame(cfg, blob + offsets[pkt], sizes[pkt], q, cd + (size_t)pkt * 8u,
-                           rows + (size_t)pkt * cfg.num_channels * row_stride, (size_t)row_stride, f,
-                           out + (size_t)pkt * out_stride);
+    const uint32_t n_scan = plan->count[kKeyScan];
+    const uint32_t first = plan->pkt_start[kKeyScan];
+    const uint64_t items = (uint64_t)n_scan * blocks_per_pkt;
+    for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const uint32_t pkt = perm[first + (uint32_t)(it / blocks_per_pkt)];
+        const alac::PktDesc q = pd[pkt];
+        if (q.status != 0 || q.route != alac::ROUTE_SPLIT) continue;
+        const uint32_t f = (uint32_t)(it % blocks_per_pkt) * blockDim.x + threadIdx.x;
+        if (f >= q.frames) continue;
+        alac::interleave_frame(cfg, blob + offsets[pkt], sizes[pkt], q, cd + (size_t)pkt * 8u,
+                               rows + (size_t)pkt * cfg.num_channels * row_stride, (size_t)row_stride, f,
+                               out + (size_t)pkt * out_stride);
+    }
 }
 
 /* packets the scan routed to the whole-packet decoder (orders 17..30): same wave mapping as alac_decode */
@@ -517,10 +524,10 @@ int reserve_workspace(alacgpu_decoder* dec, size_t n, uint32_t ppw) {
     if ((rc = dec->plan.ensure(sizeof(Plan)))) return rc;
     if ((rc = dec->cls.ensure((n ? n : 1) * sizeof(uint16_t)))) return rc;
     if ((rc = dec->perm.ensure((n ? n : 1) * sizeof(uint32_t)))) return rc;
+    const size_t ns = (n ? n : 1) * 8;
+    if ((rc = dec->cd.ensure(ns * sizeof(alac::ChanDesc)))) return rc;
+    if ((rc = dec->pd.ensure((n ? n : 1) * sizeof(alac::PktDesc)))) return rc;
     if (dec->cfg.num_channels > 2) {
-        const size_t ns = (n ? n : 1) * 8;
-        if ((rc = dec->cd.ensure(ns * sizeof(alac::ChanDesc)))) return rc;
-        if ((rc = dec->pd.ensure((n ? n : 1) * sizeof(alac::PktDesc)))) return rc;
         if ((rc = dec->plan2.ensure(sizeof(Plan)))) return rc;
         if ((rc = dec->keys2.ensure(ns * sizeof(uint16_t)))) return rc;
         if ((rc = dec->perm2.ensure(ns * sizeof(uint32_t)))) return rc;
@@ -557,27 +564,32 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
                        d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw, (alac::ChanDesc*)dec->cd.p,
                        (alac::PktDesc*)dec->pd.p);
     HIP_TRY(hipGetLastError());
-    if (dec->cfg.num_channels > 2) {
-        /* split pipeline: the scan ran inside alac_decode; now one lane per channel, then the interleave */
-        Plan* plan2 = (Plan*)dec->plan2.p;
-        const size_t n_slots = n * 8;
-        const uint32_t nb2 = (uint32_t)((n_slots + 255) / 256);
-        const uint32_t ppw2 = pick_ppw(n * dec->cfg.num_channels);
+    if (dec->cfg.kb != 0) {
+        /* irregular packets were only scanned by alac_decode (status, frames, channel descriptors) */
         const uint64_t rs = row_stride_of(dec->cfg.frame_length);
         const uint32_t bpp = (dec->cfg.frame_length + 255u) / 256u;
-        HIP_TRY(hipMemsetAsync(plan2, 0, sizeof(Plan), dec->stream));
-        hipLaunchKernelGGL(alac_task_classify, dim3(nb2), dim3(256), 0, dec->stream, c, (const alac::ChanDesc*)dec->cd.p,
-                           (const alac::PktDesc*)dec->pd.p, (const uint16_t*)dec->cls.p, (uint32_t)n_slots,
-                           (uint16_t*)dec->keys2.p, plan2);
-        hipLaunchKernelGGL(alac_plan, dim3(1), dim3(256), 0, dec->stream, plan2, ppw2);
-        hipLaunchKernelGGL(alac_scatter, dim3(nb2), dim3(256), 0, dec->stream, (const uint16_t*)dec->keys2.p,
-                           (uint32_t)n_slots, plan2, (uint32_t*)dec->perm2.p);
-        hipLaunchKernelGGL(alac_chan_decode, dim3((uint32_t)max_waves(n_slots, ppw2)), dim3(kWave), 0, dec->stream, c, d_blob,
-                           d_offsets, d_sizes, (const uint32_t*)dec->perm2.p, (const Plan*)plan2,
-                           (const alac::ChanDesc*)dec->cd.p, (int32_t*)dec->rows.p, rs, ppw2);
-        hipLaunchKernelGGL(alac_interleave, dim3((uint32_t)(n * bpp)), dim3(256), 0, dec->stream, c, d_blob, d_offsets, d_sizes,
-                           (const uint16_t*)dec->cls.p, (const alac::ChanDesc*)dec->cd.p, (const alac::PktDesc*)dec->pd.p,
-                           (const int32_t*)dec->rows.p, rs, d_out, (uint64_t)out_stride, bpp);
+        if (dec->cfg.num_channels > 2) {
+            /* split pipeline: one lane per channel, sorted by predictor order */
+            Plan* plan2 = (Plan*)dec->plan2.p;
+            const size_t n_slots = n * 8;
+            const uint32_t nb2 = (uint32_t)((n_slots + 255) / 256);
+            const uint32_t ppw2 = pick_ppw(n * dec->cfg.num_channels);
+            HIP_TRY(hipMemsetAsync(plan2, 0, sizeof(Plan), dec->stream));
+            hipLaunchKernelGGL(alac_task_classify, dim3(nb2), dim3(256), 0, dec->stream, c, (const alac::ChanDesc*)dec->cd.p,
+                               (const alac::PktDesc*)dec->pd.p, (const uint16_t*)dec->cls.p, (uint32_t)n_slots,
+                               (uint16_t*)dec->keys2.p, plan2);
+            hipLaunchKernelGGL(alac_plan, dim3(1), dim3(256), 0, dec->stream, plan2, ppw2);
+            hipLaunchKernelGGL(alac_scatter, dim3(nb2), dim3(256), 0, dec->stream, (const uint16_t*)dec->keys2.p,
+                               (uint32_t)n_slots, plan2, (uint32_t*)dec->perm2.p);
+            hipLaunchKernelGGL(alac_chan_decode, dim3((uint32_t)max_waves(n_slots, ppw2)), dim3(kWave), 0, dec->stream, c,
+                               d_blob, d_offsets, d_sizes, (const uint32_t*)dec->perm2.p, (const Plan*)plan2,
+                               (const alac::ChanDesc*)dec->cd.p, (int32_t*)dec->rows.p, rs, ppw2);
+        }
+        /* PCM of the split packets (with one or two channels: of the escape-only packets) */
+        const uint32_t ib = (uint32_t)std::min<uint64_t>((uint64_t)n * bpp, 8192);
+        hipLaunchKernelGGL(alac_interleave, dim3(ib), dim3(256), 0, dec->stream, c, d_blob, d_offsets, d_sizes,
+                           (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::ChanDesc*)dec->cd.p,
+                           (const alac::PktDesc*)dec->pd.p, (const int32_t*)dec->rows.p, rs, d_out, (uint64_t)out_stride, bpp);
         hipLaunchKernelGGL(alac_legacy, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, d_offsets,
                            d_sizes, (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::PktDesc*)dec->pd.p, d_out,
                            (uint64_t)out_stride, d_frames, d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw);

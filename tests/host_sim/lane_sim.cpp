@@ -94,7 +94,7 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
                 continue;
             }
         }
-        if ((variant == -1 && cfg->num_channels > 2 && dc.kb != 0) || (variant == -2 && dc.kb != 0)) {
+        if ((variant == -1 || variant == -2) && dc.kb != 0) {
             /* split pipeline, as alacgpu.hip runs it: scan -> one lean phase per channel -> interleave */
             alac::ChanDesc cd[8];
             memset(cd, 0, sizeof(cd));
