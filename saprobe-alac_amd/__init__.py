@@ -163,7 +163,7 @@ def lib_path():
 def build(force=False):
     """Compile csrc/alacgpu.hip for gfx950 (hipcc cross-compiles without a GPU)."""
     so = lib_path()
-    srcs = [os.path.join(_CSRC, f) for f in ("alacgpu.hip", "alac_wave.h", "alac_regular.h", "alac_split.h")] + [
+    srcs = [os.path.join(_CSRC, f) for f in ("alacgpu.hip", "alac_wave.h", "alac_regular.h", "alac_split.h", "alac_duo.h")] + [
         os.path.join(_HERE, "..", "include", "alacgpu.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _CSRC, "libalacgpu.so"], stdout=subprocess.DEVNULL)

@@ -1,0 +1,339 @@
+/*
+ * alac_duo.h — regular packets decoded by a PAIR of wavefronts per 64 packets (role specialisation).
+ *
+ * Why. The per-sample step of alac_regular.h is two dependency chains — the Golomb code of sample i+1 and the
+ * predictor taps of sample i — that one wavefront cannot overlap: a lone gfx950 wave issues a dependent VALU
+ * instruction every ~8.3 cycles and an independent one every ~4.8, and the compiler's schedule keeps each chain
+ * contiguous. With ONE wave per SIMD (a 65 536-packet batch is exactly 1 024 full waves) the SIMD idles between
+ * dependent instructions; two waves on a SIMD interleave in hardware (measured: 1.62x the throughput of one).
+ * A batch has no second wave's worth of packets to give, so the step itself is cut in two:
+ *
+ *   wave A (entropy)     Golomb/Rice decode of residual chunk c (golomb.go:148-253): a serial chain, ~70
+ *                        dependent VALU instructions per sample, nothing else;
+ *   wave B (predictor)   adaptive FIR reconstruction (predictor.go:45-684) of chunk c-1, unmix (matrix.go:40-41),
+ *                        shift-byte merge, PCM packing and the LDS stager: many short independent chains.
+ *
+ * The two waves of a workgroup hold the SAME 64 packets (lane = packet in both). Residuals go A -> B through a
+ * double-buffered LDS queue of DUO_CHUNK steps x 64 lanes; one s_barrier per chunk is the only synchronisation.
+ * Iteration c: A writes R[c & 1], B reads R[(c-1) & 1]; the barrier at the end of the iteration publishes the
+ * chunk. U of a pair still goes through the HBM hand-off tile (B stores it in the U phase and loads it in the V
+ * phase): V's first bit is known only when U is fully parsed. Status and frame count come from A (it sees the
+ * entropy errors), PCM from B.
+ *
+ * ROLE_BOTH runs the same code with one caller playing both roles in turn (tests/host_sim: one lane, no
+ * barriers) so the logic is checked against the oracle in the CPU suite.
+ */
+#ifndef ALAC_DUO_H
+#define ALAC_DUO_H
+
+#include "alac_regular.h"
+
+#ifndef ALAC_DUO_STAMP
+/* profiling build only (-DALAC_DUO_PROF in alacgpu.hip): time stamps around the parts of an iteration */
+#define ALAC_DUO_STAMP(k)
+#endif
+
+namespace alac {
+
+constexpr uint32_t DUO_CHUNK = 8; /* steps per queue buffer */
+enum { ROLE_A = 0, ROLE_B = 1, ROLE_BOTH = 2 };
+
+/*
+ * One channel of a regular element. s: the lane's Golomb + reader state (role A). NA: this channel's predictor
+ * order (role B; wave-uniform), 0 = the general form for na_rt in {0..16, 31} on 16 register taps.
+ */
+template <class W, int NA, int OUT, int ROLE>
+ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
+                        uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
+                        uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb) {
+    constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
+    constexpr bool LAST = OUT == OUT_STEREO || OUT == OUT_MONO;
+    constexpr bool CPE = OUT == OUT_STEREO;
+    constexpr bool GEN = NA == 0;
+    constexpr int NR = GEN ? 16 : NA;
+    constexpr bool WRAP = !(NA == 4 || NA == 5 || NA == 6 || NA == 8); /* predictor.go:81-93 */
+    constexpr uint32_t BIAS = 0x80000000u;
+    constexpr uint32_t CH = DUO_CHUNK;
+    const uint32_t na = GEN ? na_rt : (uint32_t)NA;
+    const uint32_t kb = cfg.kb;
+    const uint32_t wb = (1u << kb) - 1u;
+    const uint32_t chan_shift = 32u - chan_bits;
+    const int32_t den_half = den_shift ? (int32_t)(1u << (den_shift - 1u)) : 0;
+    const uint32_t rnd_neg = (1u << den_shift) - 1u;
+
+    /* ---- role B state: coefficients, sign-biased history, byte packer ---- */
+    int32_t coef[NR];
+    uint32_t hb[NR + 1];
+    if (DO_B) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+            coef[j] = (!GEN || ((uint32_t)j < na && na != 31)) ? (int32_t)(int16_t)bits.get(hdr_pos + 16u + 16u * (uint32_t)j, 16) : 0;
+#pragma unroll
+        for (int j = 0; j <= NR; ++j) hb[j] = BIAS;
+    }
+    uint64_t pk_acc = 0;
+    uint32_t pk_n = 0;
+    const uint32_t bps = cfg.bps;
+    const uint64_t pk_msk = bps == 4 ? 0xffffffffull : ((1ull << (8u * bps)) - 1ull);
+    const bool merge_any = DO_B && LAST && wv.any(sb != 0);
+
+    /* A: residuals of chunk c (DynDecomp, golomb.go:167-247) */
+    auto golomb_chunk = [&](uint32_t c) {
+        const uint32_t buf = c & 1u;
+#pragma nounroll
+        for (uint32_t j = 0; j < CH; ++j) {
+            const uint32_t i = c * CH + j;
+            if (i >= n_it) break;
+            if ((i & 3u) == 0) s.rd.tick(wv); /* scalar test: bitstream ring refill, 4 steps ahead of need */
+            GolTent t;
+            gol_tentative(s, kb, i, ns, t);
+            const int32_t del = gol_commit(wv, bits, s, size, kb, wb, chan_bits, i, ns, t);
+            wv.rq_write(buf, j, del);
+        }
+    };
+    /* B: sample i is reconstructed: history; then the U hand-off tile, or unmix / shift merge / PCM.
+     * u: the U sample of frame i (pairs), sw: window on the frame's shift values (24/32-bit) */
+    auto put = [&](uint32_t i, int32_t o, int32_t u, uint64_t sw) {
+#pragma unroll
+        for (int t = NR; t >= 1; --t) hb[t] = hb[t - 1];
+        hb[0] = (uint32_t)o ^ BIAS;
+        if (!LAST) {
+            *wv.u_row(i) = o; /* dead lanes write their own unused cell */
+            return;
+        }
+        const bool on = i < ns;
+        int32_t l = o, r = 0;
+        if (CPE) {
+            const int32_t vv = o;
+            if (mix_res != 0) { /* matrix.go:40-41 */
+                l = u + vv - (ALAC_MUL24(mix_res, vv) >> mix_sh);
+                r = l - vv;
+            } else {
+                l = u;
+                r = vv;
+            }
+        }
+        if (cfg.bit_depth == 20) { /* matrix.go:77-78, 237 */
+            l = (int32_t)((uint32_t)l << 4);
+            r = (int32_t)((uint32_t)r << 4);
+        }
+        if (merge_any) { /* matrix.go:129-132, 266-268: (x << 8*bytesShifted) | shift value */
+            const uint32_t sh_l = sb ? (uint32_t)(sw >> (64u - sb)) : 0u;
+            const uint32_t sh_r = (CPE && sb) ? (uint32_t)((sw << sb) >> (64u - sb)) : 0u;
+            l = (int32_t)((uint32_t)l << sb) | (int32_t)sh_l;
+            r = (int32_t)((uint32_t)r << sb) | (int32_t)sh_r;
+        }
+        if (bps == 2 && CPE) {
+            wv.st_push_if(((uint32_t)l & 0xffffu) | ((uint32_t)r << 16), on);
+        } else {
+            /* generic widths: append bps bytes per sample, emit a dword whenever four are ready (all selects) */
+            pk_acc |= ((uint64_t)(uint32_t)l & pk_msk) << (8u * pk_n);
+            pk_n += on ? bps : 0u;
+            bool em = pk_n >= 4u;
+            wv.st_push_if((uint32_t)pk_acc, em);
+            pk_acc = em ? pk_acc >> 32 : pk_acc;
+            pk_n = em ? pk_n - 4u : pk_n;
+            if (CPE) {
+                pk_acc |= ((uint64_t)(uint32_t)r & pk_msk) << (8u * pk_n);
+                pk_n += on ? bps : 0u;
+                em = pk_n >= 4u;
+                wv.st_push_if((uint32_t)pk_acc, em);
+                pk_acc = em ? pk_acc >> 32 : pk_acc;
+                pk_n = em ? pk_n - 4u : pk_n;
+            }
+            /* a lane that is not `on` appended nothing: clear what the OR left above its valid bytes */
+            pk_acc &= pk_n ? ((1ull << (8u * pk_n)) - 1ull) : 0ull;
+        }
+        wv.st_step(); /* collective of wave B */
+    };
+    /* B: samples of chunk c (UnpcBlock, predictor.go:45-684): out[0] = residual, warm-up up to na (:53-79),
+     * copy (0) / delta (31) modes, then the adaptive taps */
+    auto predict_chunk = [&](uint32_t c) {
+        const uint32_t buf = c & 1u;
+        const bool simple = GEN && (na == 0 || na == 31);
+        /* both shift values of a frame sit side by side (decoder.go:492-502): one window */
+        const uint32_t sstep = (CPE ? 2u : 1u) * sb;
+        if (!simple && c * CH > na && (c + 1u) * CH <= n_it) {
+            /* steady state, a whole chunk: straight-line code; residuals (LDS), U samples and shift values
+             * (HBM/L2) are all requested up front and their latency hides behind the taps of the first steps;
+             * the history shift becomes register renaming across the unrolled steps */
+            constexpr uint32_t UN = NR <= 8 ? CH : CH / 2u; /* long predictors: half chunks, or registers run out */
+#pragma nounroll
+            for (uint32_t g = 0; g < CH; g += UN) {
+                int32_t dv[UN], uv[UN];
+                uint64_t sv[UN];
+#pragma unroll
+                for (uint32_t j = 0; j < UN; ++j) {
+                    dv[j] = wv.rq_read(buf, g + j);
+                    uv[j] = 0;
+                    sv[j] = 0;
+                    if (CPE) uv[j] = *wv.u_row(c * CH + g + j);
+                    if (merge_any) sv[j] = bits.window(shift_pos + (c * CH + g + j) * sstep);
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < UN; ++j)
+                    put(c * CH + g + j,
+                        predict_narrow<NR, GEN, WRAP>(coef, hb, na, dv[j], den_shift, den_half, rnd_neg, chan_shift), uv[j],
+                        sv[j]);
+            }
+            return;
+        }
+#pragma nounroll
+        for (uint32_t j = 0; j < CH; ++j) {
+            const uint32_t i = c * CH + j;
+            if (i >= n_it) break;
+            const int32_t del = wv.rq_read(buf, j);
+            int32_t o;
+            if (i == 0 || (GEN && na == 0)) o = del;
+            else if (i <= na || (GEN && na == 31)) o = sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
+            else o = predict_narrow<NR, GEN, WRAP>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
+            put(i, o, CPE ? *wv.u_row(i) : 0, merge_any ? bits.window(shift_pos + i * sstep) : 0ull);
+        }
+    };
+
+    /* iteration c: A produces chunk c while B consumes chunk c-1; the barrier publishes R[c & 1] */
+    const uint32_t nch = (n_it + CH - 1u) / CH;
+    for (uint32_t c = 0; c <= nch; ++c) {
+        ALAC_DUO_STAMP(0);
+#ifndef ALAC_EXP_DUO_NO_GOLOMB
+        if (DO_A) {
+            if (c < nch) golomb_chunk(c);
+        }
+#endif
+        ALAC_DUO_STAMP(1);
+#ifndef ALAC_EXP_DUO_NO_B
+        if (DO_B) {
+            if (c >= 1u) predict_chunk(c - 1u);
+        }
+#endif
+        ALAC_DUO_STAMP(2);
+        ALAC_DUO_STAMP(3);
+        wv.duo_sync();
+        ALAC_DUO_STAMP(4);
+    }
+    if (DO_B && LAST) wv.st_tail(pk_acc, pk_n); /* bytes of the last, incomplete dword */
+    if (!LAST) wv.duo_sync_mem();               /* B's tile stores land before it reads them back as V's partner */
+}
+
+/* the order switch is scalar: NA is wave-uniform by construction of the waves. Role A never looks at the order. */
+template <class W, int OUT, int ROLE>
+ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size,
+                           uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
+                           int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb) {
+#define ALAC_DUO_CASE(N)                                                                                              \
+    case N:                                                                                                           \
+        duo_phase<W, N, OUT, ROLE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, \
+                                   na, shift_pos, sb);                                                                \
+        break;
+    if (ROLE == ROLE_A) {
+        duo_phase<W, 0, OUT, ROLE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na,
+                                   shift_pos, sb);
+        return;
+    }
+    switch (na) {
+        ALAC_DUO_CASE(1)
+        ALAC_DUO_CASE(2)
+        ALAC_DUO_CASE(3)
+        ALAC_DUO_CASE(4)
+        ALAC_DUO_CASE(5)
+        ALAC_DUO_CASE(6)
+        ALAC_DUO_CASE(7)
+        ALAC_DUO_CASE(8)
+        ALAC_DUO_CASE(9)
+        ALAC_DUO_CASE(10)
+        ALAC_DUO_CASE(11)
+        ALAC_DUO_CASE(12)
+        ALAC_DUO_CASE(13)
+        ALAC_DUO_CASE(14)
+        ALAC_DUO_CASE(15)
+        ALAC_DUO_CASE(16)
+        default:
+            duo_phase<W, 0, OUT, ROLE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh,
+                                       na, shift_pos, sb);
+            break;
+    }
+#undef ALAC_DUO_CASE
+}
+
+/*
+ * decode_regular_duo: same contract as decode_regular (alac_regular.h) for the caller playing role A (or both):
+ * every lane holds a regular packet with the same key = numU*32 + numV, lanes without a packet pass live = false;
+ * returns the status word and sets *frames_out. The caller playing role B passes the same arguments; its return
+ * value and *frames_out mean nothing.
+ */
+template <class W, int ROLE>
+ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
+                                    uint8_t* out, uint32_t* frames_out) {
+    constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
+    const Bits bits{pkt, size};
+    const bool cpe = cfg.num_channels == 2;
+    const uint32_t na_u = key >> 5, na_v = key & 31u;
+
+    RegLane<W> s;
+    s.rd.init(pkt, size);
+    s.err = 0;
+    s.max_pos = size * 8u;
+
+    /* header (accepted by classify_regular, so no error can arise here): decoder.go:213-235, 421-450 */
+    uint32_t pos = 23;
+    uint32_t ns = 0;
+    if (live) {
+        ns = cfg.frame_length;
+        if (bits.get(19, 4) >> 3) {
+            ns = bits.get(pos, 32);
+            pos += 32;
+        }
+    }
+    const int32_t mix_bits = (int32_t)bits.get(pos, 8);
+    const int32_t mix_res = (int32_t)(int8_t)bits.get(pos + 8, 8);
+    const uint32_t mix_sh = (uint32_t)mix_bits > 31u ? 31u : (uint32_t)mix_bits;
+    const uint32_t hdr_u = pos + 16u;
+    const uint32_t hdr_v = hdr_u + 16u + 16u * na_u;
+    const uint32_t hu = bits.get(hdr_u, 16);
+    const uint32_t hv = bits.get(hdr_v, 16);
+    const uint32_t bs = (bits.get(19, 4) >> 1) & 3u;
+    const uint32_t shift_pos = cpe ? hdr_v + 16u + 16u * na_v : hdr_v; /* decoder.go:289-293, 453-457 */
+    s.pos = shift_pos + bs * 8u * (cpe ? 2u : 1u) * ns;
+    const uint32_t chan_bits = cfg.bit_depth - 8u * bs + (cpe ? 1u : 0u);
+    /* the 16- and 20-bit writers ignore the shift buffer (matrix.go:30,66) */
+    const uint32_t sb = (cfg.bit_depth == 24 || cfg.bit_depth == 32) ? bs * 8u : 0u;
+    const uint32_t n_it = wv.max_u32(ns);
+    if (DO_B && live) wv.st_begin(out);
+
+    /* ---- U (or the mono channel) ---- */
+    s.mean = cfg.mb;
+    s.zmode = 0;
+    s.zrem = 0;
+    s.pb = (cfg.pb * ((hu >> 5) & 7u)) / 4u; /* decoder.go:299 */
+    if (DO_A) s.rd.start(wv, live ? s.pos : 0u);
+    if (cpe) duo_phase_na<W, OUT_UTILE, ROLE>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
+    else duo_phase_na<W, OUT_MONO, ROLE>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
+    uint32_t err_chan = 0;
+    /* ---- V ---- */
+    if (cpe) {
+        const bool u_failed = s.err != 0;
+        if (!u_failed && ((s.pos >> 3) > size + 4u || (s.pos >> 3) > size)) s.err = ST_MALFORMED; /* DynDecomp entry */
+        const int32_t err_u = s.err;
+        s.mean = cfg.mb;
+        s.zmode = 0;
+        s.zrem = 0;
+        s.pb = (cfg.pb * ((hv >> 5) & 7u)) / 4u;
+        if (DO_A) s.rd.start(wv, (live && s.err == 0) ? s.pos : 0u);
+        duo_phase_na<W, OUT_STEREO, ROLE>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+        if (err_u == 0 && s.err != 0) err_chan = 1;
+    }
+    if (DO_B && live) (void)wv.st_finish();
+    if (!DO_A || !live) return 0;
+    if (s.err) {
+        *frames_out = 0;
+        if (s.err == ST_MALFORMED) return ST_MALFORMED;
+        const uint32_t stage = cpe ? (uint32_t)(err_chan == 0 ? ALACGPU_STAGE_ENTROPY_U : ALACGPU_STAGE_ENTROPY_V)
+                                   : (uint32_t)ALACGPU_STAGE_ENTROPY;
+        return ALACGPU_STATUS(s.err, cpe ? ALACGPU_CTX_CPE : ALACGPU_CTX_SCE, stage);
+    }
+    *frames_out = ns;
+    return 0;
+}
+
+} /* namespace alac */
+#endif

@@ -45,6 +45,14 @@
 /* -1 / 0 / +1: one v_med3_i32 on the GPU */
 #define ALAC_SIGN(x) (((x) > 0) - ((x) < 0))
 #endif
+#ifndef ALAC_SUBSAT
+/* unsigned a - b, 0 when b > a: v_sub_u32 ... clamp on the GPU */
+#define ALAC_SUBSAT(a, b) ((a) > (b) ? (a) - (b) : 0u)
+#endif
+#ifndef ALAC_MULU24
+/* exact when both operands fit 24-bit unsigned: v_mul_u32_u24 / v_mad_u32_u24 on the GPU */
+#define ALAC_MULU24(a, b) ((uint32_t)(a) * (uint32_t)(b))
+#endif
 
 namespace alac {
 
@@ -287,6 +295,92 @@ struct GolTent {
     bool dec, slow, on, inrun;
 };
 
+/* ---- one residual (DynDecomp, golomb.go:167-247) in two halves ------------------------------------------------
+ * gol_tentative(): pure ALU, no branch, no state change. gol_commit(): the one rare branch (escape code, start of
+ * a zero run, overrun), then the state update by selects and the reader slide. i = sample index, ns = the lane's
+ * sample count (i >= ns: a dead step). */
+template <class W>
+ALAC_DEV void gol_tentative(const RegLane<W>& s, uint32_t kb, uint32_t i, uint32_t ns, GolTent& t) {
+    t.on = i < ns && s.err == 0;
+    t.inrun = s.zrem != 0;
+    t.dec = t.on && !t.inrun;
+    uint32_t m = s.mean >> 9;
+    const uint32_t k = umin(31u - clz32(m + 3u), kb);
+    m = (1u << k) - 1u;
+    const uint32_t w = s.rd.window(s.pos);
+    const uint32_t pre = clz32(~w);
+    const uint32_t v = (w << ((pre + 1u) & 31u)) >> (32u - k);
+    const bool big = v >= 2;
+    const uint32_t n = pre * m + (big ? v - 1u : 0u);
+    const uint32_t nd = n + s.zmode;
+    t.mean2 = s.pb * nd + s.mean - ((s.pb * s.mean) >> 9); /* golomb.go:215 */
+    if (n > 0xffffu) t.mean2 = 0xffffu;
+    t.slow = t.dec && (s.pos >= s.max_pos || pre >= 9 || ((t.mean2 << 2) < 512u && i + 1u < ns));
+    const int32_t half = (int32_t)((nd + 1u) >> 1); /* golomb.go:206-209 */
+    t.del = t.inrun ? 0 : ((nd & 1u) ? -half : half);
+    t.pos2 = s.pos + pre + k + (big ? 1u : 0u); /* prefix + 1, then k bits (v >= 2) or k - 1 */
+}
+template <class W>
+ALAC_DEV int32_t gol_commit(W& wv, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
+                            uint32_t chan_bits, uint32_t i, uint32_t ns, const GolTent& t) {
+    int32_t del = t.del;
+    if (wv.any(t.slow)) {
+        if (t.slow) {
+            del = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns);
+            s.rd.reseek(wv, s.pos);
+        }
+    }
+    const bool ok = t.dec && !t.slow;
+    s.pos = ok ? t.pos2 : s.pos;
+    s.mean = ok ? t.mean2 : s.mean;
+    s.zmode = ok ? 0u : s.zmode;
+    s.zrem = (t.on && t.inrun) ? s.zrem - 1u : s.zrem;
+    s.rd.slide(wv, s.pos);
+    return del;
+}
+
+/* ---- predictor step for i > na (UnpcBlock, predictor.go:99-684), chanBits <= 23 ---------------------------------
+ * hb[j] = out[i-1-j] ^ BIAS (sign-biased history: |a - b| of biased values is one unsigned sad). Taps walked from
+ * the highest down. The adaptation is sign-normalised: D0 = |del| shrinks (saturating at 0) by t_j = (na-j) *
+ * ((|d_j| + rnd) >> denShift) tap after tap and tap j adapts while something of D0 is left. chanBits <= 23 keeps
+ * q < 2^23 and t_j < 2^27: nothing wraps, which is what makes this equal to the reference's signed countdown.
+ * GEN: the wave-uniform order na on NR = 16 register taps; WRAP: int16 coefficients (predictor.go:664,675). */
+template <int NR, bool GEN, bool WRAP>
+ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1], uint32_t na, int32_t del,
+                                uint32_t den_shift, int32_t den_half, uint32_t rnd_neg, uint32_t chan_shift) {
+    constexpr uint32_t BIAS = 0x80000000u;
+    uint32_t topb = hb[NR];
+    if (GEN) {
+#pragma unroll
+        for (int j = 1; j < NR; ++j)
+            if (na == (uint32_t)j) ALAC_PICK(topb, hb[j]); /* scalar branch: na is wave-uniform */
+    }
+    /* no compares on the hot path (a v_cmp / v_cndmask pair costs a lone wave ~17 cycles, plain ALU ops ~5):
+     * everything that depends on the sign of the residual is derived from its sign mask */
+    const uint32_t sgnm = (uint32_t)(del >> 31);          /* ~0 for del < 0 */
+    const uint32_t rnd = rnd_neg & sgnm;
+    /* delta_j = sign(del) * -sign(d_j) as (sd ^ nmask) + pm: identity for del < 0, negation otherwise */
+    const uint32_t nmask = ~sgnm;
+    const uint32_t pm = 1u + sgnm;
+    uint32_t rem = ((uint32_t)del ^ sgnm) - sgnm;         /* D0 = |del|: what is left of it after the taps above */
+    int32_t dot = 0;
+#pragma unroll
+    for (int j = NR - 1; j >= 0; --j) {
+        if (GEN && (uint32_t)j >= na) continue; /* scalar branch: taps the order does not have */
+        const int32_t d = (int32_t)(topb - hb[j]); /* top - out[i-1-j]; the bias cancels */
+        dot += ALAC_MUL24(coef[j], d);             /* uses coef[j] before its update */
+        const int32_t sd = ALAC_SIGN(d);
+        const int32_t delta = (int32_t)(((uint32_t)sd ^ nmask) + pm);
+        const uint32_t q = ALAC_SAD(topb, hb[j], rnd) >> den_shift;
+        const int32_t go = (int32_t)umin(rem, 1u); /* tap j adapts while the budget is not used up */
+        const int32_t cj = coef[j] + ALAC_MUL24(delta, go);
+        coef[j] = WRAP ? (int32_t)(int16_t)cj : cj; /* predictor.go:664,675 */
+        rem = ALAC_SUBSAT(rem, ALAC_MULU24(q, na - (uint32_t)j));
+    }
+    const int32_t acc = den_half - dot;
+    return sext_cs(del + (int32_t)(topb ^ BIAS) + (acc >> den_shift), chan_shift);
+}
+
 /* what a phase does with the reconstructed samples */
 enum { OUT_UTILE = 0,  /* U of a pair: hand-off tile */
        OUT_STEREO = 1, /* V of a pair: unmix with U, PCM */
@@ -344,48 +438,10 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
         return mode != 0 ? dd : del;
     };
 
-    /* ---- one residual (DynDecomp, golomb.go:167-247) in two halves ------------------------------------------
-     * tentative(): pure ALU, no branch, no state change. commit(): the one rare branch (escape code, start of a
-     * zero run, overrun), then the state update by selects and the reader slide. Splitting it lets the main
-     * loop put the tentative half of sample i+1 in the same basic block as the predictor taps of sample i: two
-     * independent dependency chains for the scheduler to interleave (a lone wave issues a dependent VALU op every
-     * ~8.3 cycles, an independent one every ~4.8: profiles/microbench). */
-    auto tentative = [&](uint32_t i, GolTent& t) {
-        t.on = i < ns && s.err == 0;
-        t.inrun = s.zrem != 0;
-        t.dec = t.on && !t.inrun;
-        uint32_t m = s.mean >> 9;
-        const uint32_t k = umin(31u - clz32(m + 3u), kb);
-        m = (1u << k) - 1u;
-        const uint32_t w = s.rd.window(s.pos);
-        const uint32_t pre = clz32(~w);
-        const uint32_t v = (w << ((pre + 1u) & 31u)) >> (32u - k);
-        const bool big = v >= 2;
-        const uint32_t n = pre * m + (big ? v - 1u : 0u);
-        const uint32_t nd = n + s.zmode;
-        t.mean2 = s.pb * nd + s.mean - ((s.pb * s.mean) >> 9); /* golomb.go:215 */
-        if (n > 0xffffu) t.mean2 = 0xffffu;
-        t.slow = t.dec && (s.pos >= s.max_pos || pre >= 9 || ((t.mean2 << 2) < 512u && i + 1u < ns));
-        const int32_t half = (int32_t)((nd + 1u) >> 1); /* golomb.go:206-209 */
-        t.del = t.inrun ? 0 : ((nd & 1u) ? -half : half);
-        t.pos2 = s.pos + pre + k + (big ? 1u : 0u); /* prefix + 1, then k bits (v >= 2) or k - 1 */
-    };
-    auto commit = [&](uint32_t i, GolTent& t) -> int32_t {
-        int32_t del = t.del;
-        if (wv.any(t.slow)) {
-            if (t.slow) {
-                del = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns);
-                s.rd.reseek(wv, s.pos);
-            }
-        }
-        const bool ok = t.dec && !t.slow;
-        s.pos = ok ? t.pos2 : s.pos;
-        s.mean = ok ? t.mean2 : s.mean;
-        s.zmode = ok ? 0u : s.zmode;
-        s.zrem = (t.on && t.inrun) ? s.zrem - 1u : s.zrem;
-        s.rd.slide(wv, s.pos);
-        return del;
-    };
+    /* one residual in two halves (gol_tentative / gol_commit above): the main loop puts the tentative half of
+     * sample i+1 in the same basic block as the predictor taps of sample i */
+    auto tentative = [&](uint32_t i, GolTent& t) { gol_tentative(s, kb, i, ns, t); };
+    auto commit = [&](uint32_t i, GolTent& t) -> int32_t { return gol_commit(wv, bits, s, size, kb, wb, chan_bits, i, ns, t); };
     /* ---- predictor step for i > na (UnpcBlock, predictor.go:99-684) -------------------------------------------
      * Taps walked from the highest down. The adaptation is sign-normalised: D0 = |del| shrinks by
      * t_j = (na-j) * ((|d_j| + rnd) >> denShift) tap after tap and tap j adapts while the running total of the
@@ -424,34 +480,7 @@ ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<
             }
             return o;
         }
-        uint32_t topb = hb[NR];
-        if (GEN) {
-#pragma unroll
-            for (int j = 1; j < NR; ++j)
-                if (na == (uint32_t)j) ALAC_PICK(topb, hb[j]); /* scalar branch: na is wave-uniform */
-        }
-        const bool neg = del < 0;
-        const uint32_t big_d0 = (uint32_t)(neg ? -del : del);
-        const uint32_t rnd = neg ? rnd_neg : 0u;
-        /* delta_j = sign(del) * -sign(d_j) as (sd ^ nmask) + pm: identity for del < 0, negation otherwise */
-        const uint32_t nmask = neg ? 0u : 0xffffffffu;
-        const uint32_t pm = neg ? 0u : 1u;
-        int32_t dot = 0;
-        uint32_t run = 0;
-#pragma unroll
-        for (int j = NR - 1; j >= 0; --j) {
-            if (GEN && (uint32_t)j >= na) continue; /* scalar branch: taps the order does not have */
-            const int32_t d = (int32_t)(topb - hb[j]); /* top - out[i-1-j]; the bias cancels */
-            dot += ALAC_MUL24(coef[j], d);             /* uses coef[j] before its update */
-            const int32_t sd = ALAC_SIGN(d);
-            const int32_t delta = (int32_t)(((uint32_t)sd ^ nmask) + pm);
-            const uint32_t q = ALAC_SAD(topb, hb[j], rnd) >> den_shift;
-            const int32_t step = run < big_d0 ? delta : 0; /* a select of two ready values: no branch */
-            coef[j] = WRAP ? (int32_t)(int16_t)(coef[j] + step) : coef[j] + step; /* predictor.go:664,675 */
-            run += (uint32_t)ALAC_MUL24((int32_t)q, (int32_t)na - j);
-        }
-        const int32_t acc = den_half - dot;
-        return sext_cs(del + (int32_t)(topb ^ BIAS) + (acc >> den_shift), chan_shift);
+        return predict_narrow<NR, GEN, WRAP>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
     };
     /* ---- history, hand-off / unmix / PCM of sample i ------------------------------------------------------------ */
     auto emit = [&](uint32_t i, int32_t o, bool on, int32_t u_pre, uint32_t sh_l, uint32_t sh_r) {

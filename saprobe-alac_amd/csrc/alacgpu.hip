@@ -34,6 +34,8 @@ __device__ __forceinline__ int32_t alac_sign_med3(int32_t x) {
     return r;
 }
 #define ALAC_SIGN(x) alac_sign_med3(x)
+#define ALAC_SUBSAT(a, b) __builtin_elementwise_sub_sat((uint32_t)(a), (uint32_t)(b))
+#define ALAC_MULU24(a, b) __umul24((unsigned)(a), (unsigned)(b))
 #define ALAC_PICK(dst, src) asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(src))
 typedef uint32_t alac_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 #define ALAC_LOAD4(q, a, b, c, d)                                                       \
@@ -44,9 +46,20 @@ typedef uint32_t alac_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
         (c) = v_.z;                                                                     \
         (d) = v_.w;                                                                     \
     } while (0)
+#ifdef ALAC_DUO_PROF
+/* profiling build: cycles (s_memtime) between the stamps of alac_duo.h, summed per role over all waves */
+__device__ unsigned long long g_duo_prof[16];
+#define ALAC_DUO_STAMP(k)                                                   \
+    do {                                                                    \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
+        if ((k) > 0) wv.prof[(k) - 1] += t_ - wv.prof_t;                     \
+        wv.prof_t = t_;                                                     \
+    } while (0)
+#endif
 #include "alac_wave.h"
 #include "alac_regular.h"
 #include "alac_split.h"
+#include "alac_duo.h"
 
 namespace {
 
@@ -81,6 +94,10 @@ struct Plan {
 __shared__ uint32_t s_rows[kWave * kRowStride];                                  /* PCM stager rows */
 __shared__ unsigned long long s_optr[kWave];                                     /* PCM slot of each lane's packet */
 __shared__ __attribute__((aligned(16))) uint32_t s_ring[kWave * kRingStride];    /* bitstream rings */
+/* role queues of the wave pair (alac_duo.h): residuals A -> B and samples B -> A, double-buffered chunks */
+constexpr uint32_t kQ = alac::DUO_CHUNK;
+__shared__ int32_t s_rq[2 * kQ * kWave];
+__shared__ int32_t s_sq[2 * kQ * kWave];
 
 /* ---- gfx950 wave policy for alac::decode_wave --------------------------------------------------------- */
 struct GpuWave {
@@ -90,6 +107,9 @@ struct GpuWave {
     uint32_t lane, wcnt, flushed;
     uint32_t ppw;              /* packets (= live lanes) per wave; also the row stride of the HBM tiles */
     uint32_t u_stride;         /* ppw, or 0 for lanes >= ppw: they own one dummy cell behind the tile */
+#ifdef ALAC_DUO_PROF
+    unsigned long long prof[4] = {0, 0, 0, 0}, prof_t = 0;
+#endif
 
     ALAC_DEV bool any(bool p) const { return __ballot(p) != 0ull; }
     ALAC_DEV uint32_t max_u32(uint32_t v) const {
@@ -98,7 +118,8 @@ struct GpuWave {
             const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
             v = t > v ? t : v;
         }
-        return v;
+        /* every lane holds the maximum: hand it back as a scalar, so loops bounded by it are uniform */
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     }
     ALAC_DEV void st_begin(uint8_t* out) {
         my_out = out;
@@ -156,6 +177,19 @@ struct GpuWave {
         *reinterpret_cast<uint4*>(&s_ring[lane * kRingStride + (slot >> 2) * 4u]) = make_uint4(a, b, c, d);
     }
     ALAC_DEV uint32_t ring_read(uint32_t slot) const { return s_ring[lane * kRingStride + slot]; }
+    /* role queues: row j of buffer buf holds step j of the chunk for all 64 lanes (conflict-free) */
+    ALAC_DEV void rq_write(uint32_t buf, uint32_t j, int32_t v) { s_rq[(buf * kQ + j) * kWave + lane] = v; }
+    ALAC_DEV int32_t rq_read(uint32_t buf, uint32_t j) const { return s_rq[(buf * kQ + j) * kWave + lane]; }
+    ALAC_DEV void sq_write(uint32_t buf, uint32_t j, int32_t v) { s_sq[(buf * kQ + j) * kWave + lane] = v; }
+    ALAC_DEV int32_t sq_read(uint32_t buf, uint32_t j) const { return s_sq[(buf * kQ + j) * kWave + lane]; }
+    /* chunk hand-over between the two waves of the workgroup: LDS traffic only, so outstanding global loads
+     * (ring refills, U prefetch) and stores (U tile) are NOT waited for — __syncthreads() would drain them */
+    ALAC_DEV void duo_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+    /* end of the U phase: wave B's tile stores must have landed before wave A loads them */
+    ALAC_DEV void duo_sync_mem() {
+        __threadfence_block();
+        __syncthreads();
+    }
     ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * u_stride; }
     ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * ppw; }
 };
@@ -234,7 +268,8 @@ alac_scatter(const uint16_t* __restrict__ keys, uint32_t n, Plan* plan, uint32_t
     if (i < n && key != alac::TASK_NONE) perm[base[key] + local] = i;
 }
 
-__global__ void __launch_bounds__(kWave)
+/* two waves per SIMD (four workgroups per CU) is what the wave pair is built for: cap the register budget there */
+__global__ void __launch_bounds__(2 * kWave, 2)
 alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
             const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
             uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
@@ -248,7 +283,9 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     for (uint32_t t = 1; t < plan->nk; ++t)
         if (plan->list_wave0[t] <= b) e = t;
     const uint32_t key = plan->list_key[e];
-    const uint32_t lane = threadIdx.x;
+    /* two waves per workgroup, the same 64 packets in both (alac_duo.h): wave 0 = role A, wave 1 = role B */
+    const uint32_t lane = threadIdx.x & (kWave - 1u);
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t idx = (b - plan->list_wave0[e]) * ppw + lane;
     const bool live = lane < ppw && idx < plan->count[key];
     const uint32_t pkt = live ? perm[plan->pkt_start[key] + idx] : 0u;
@@ -273,7 +310,24 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     /* the key is wave-uniform (one key per block): scalar branches pick the variant */
     const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
     if (ukey < 1024u) {
-        st = alac::decode_regular<GpuWave>(wv, cfg, ukey, live, p, size, o, &frames);
+        if (role != 0u) {
+            (void)alac::decode_regular_duo<GpuWave, alac::ROLE_B>(wv, cfg, ukey, live, p, size, o, &frames);
+#ifdef ALAC_DUO_PROF
+            if (lane == 0)
+                for (int k = 0; k < 4; ++k) atomicAdd(&g_duo_prof[8 + k], wv.prof[k]);
+#endif
+            return;
+        }
+        /* the entropy chain is the critical path of the pair: it issues whenever it can, the predictor wave
+         * (many independent instructions) fills the slots in between */
+        __builtin_amdgcn_s_setprio(3);
+        st = alac::decode_regular_duo<GpuWave, alac::ROLE_A>(wv, cfg, ukey, live, p, size, o, &frames);
+#ifdef ALAC_DUO_PROF
+        if (lane == 0)
+            for (int k = 0; k < 4; ++k) atomicAdd(&g_duo_prof[k], wv.prof[k]);
+#endif
+    } else if (role != 0u) {
+        return; /* irregular packets: one wave walks them */
 #ifndef ALAC_EXP_NO_SCAN
     } else if (ukey == kKeyScan) {
         /* split pipeline, step 1: status, frame count and channel descriptors; PCM comes from alac_interleave */
@@ -559,7 +613,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
                        (uint32_t*)dec->perm.p);
     const uint32_t slot = (uint32_t)(dec->launches % kTimingSlots);
     HIP_TRY(hipEventRecord(dec->ev_start[slot], dec->stream));
-    hipLaunchKernelGGL(alac_decode, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, d_offsets,
+    hipLaunchKernelGGL(alac_decode, dim3((uint32_t)max_waves(n, ppw)), dim3(2 * kWave), 0, dec->stream, c, d_blob, d_offsets,
                        d_sizes, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride, d_frames,
                        d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw, (alac::ChanDesc*)dec->cd.p,
                        (alac::PktDesc*)dec->pd.p);
@@ -842,6 +896,16 @@ int alacgpu_synchronize(alacgpu_decoder* d) {
 }
 
 const char* alacgpu_last_error(void) { return g_err; }
+
+#ifdef ALAC_DUO_PROF
+/* profiling build only: read and clear the stamp sums ([0..3] role A, [8..11] role B) */
+int alacgpu_debug_prof(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_duo_prof), sizeof(g_duo_prof)) != hipSuccess) return ALACGPU_E_HIP;
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_duo_prof), z, sizeof(z)) != hipSuccess) return ALACGPU_E_HIP;
+    return ALACGPU_E_OK;
+}
+#endif
 
 const char* alacgpu_version(void) { return "alacgpu 0.2.0 gfx950"; }
 

@@ -48,7 +48,7 @@ def lane_sim(oracle):
     d = os.path.join(ROOT, "tests", "host_sim")
     so = os.path.join(d, "liblane_sim.so")
     srcs = [os.path.join(d, "lane_sim.cpp")] + [os.path.join(ROOT, "saprobe-alac_amd", "csrc", h)
-                                                for h in ("alac_wave.h", "alac_regular.h", "alac_split.h")]
+                                                for h in ("alac_wave.h", "alac_regular.h", "alac_split.h", "alac_duo.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-fwrapv", "-fPIC", "-std=c++17", "-Wno-unknown-pragmas", "-shared",
                                "-o", so, srcs[0]])

@@ -15,6 +15,7 @@
 #include "../../saprobe-alac_amd/csrc/alac_wave.h"
 #include "../../saprobe-alac_amd/csrc/alac_regular.h"
 #include "../../saprobe-alac_amd/csrc/alac_split.h"
+#include "../../saprobe-alac_amd/csrc/alac_duo.h"
 
 namespace {
 
@@ -50,6 +51,14 @@ struct HostWave {
         ring[slot + 3] = d;
     }
     uint32_t ring_read(uint32_t slot) const { return ring[slot]; }
+    /* role queues of alac_duo.h: one lane, both roles played by the same caller, so the barriers are no-ops */
+    int32_t rq[2][alac::DUO_CHUNK] = {{0}}, sq[2][alac::DUO_CHUNK] = {{0}};
+    void rq_write(uint32_t buf, uint32_t j, int32_t v) { rq[buf][j] = v; }
+    int32_t rq_read(uint32_t buf, uint32_t j) const { return rq[buf][j]; }
+    void sq_write(uint32_t buf, uint32_t j, int32_t v) { sq[buf][j] = v; }
+    int32_t sq_read(uint32_t buf, uint32_t j) const { return sq[buf][j]; }
+    void duo_sync() {}
+    void duo_sync_mem() {}
     int32_t* u_row(uint32_t i) { return &u_tile[i]; }
     int32_t* g_slot(uint32_t k) { return &g_tile[k]; }
 };
@@ -57,9 +66,10 @@ struct HostWave {
 }  // namespace
 
 /* variant: 0..3 = force that class's generic variant (any class must decode any packet correctly);
- *          -1   = route like alacgpu.hip does (lean decoder for regular packets, split pipeline for > 2 channels,
- *                 whole-packet decoder otherwise);
- *          -2   = split pipeline for every non-regular packet, whatever the channel count.
+ *          -1   = route like alacgpu.hip does (wave-pair decoder of alac_duo.h for regular packets, split pipeline
+ *                 for > 2 channels, whole-packet decoder otherwise);
+ *          -2   = split pipeline for every non-regular packet, whatever the channel count;
+ *          -3   = like -1 with the single-wave lean decoder (decode_regular) for regular packets.
  * classes_out (may be null) gets the sort key / route. */
 extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* blob, const uint64_t* offsets,
                                      const uint32_t* sizes, size_t n, uint8_t* out, size_t out_stride,
@@ -90,11 +100,15 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
             const uint32_t key = alac::classify_regular(dc, p, sizes[i]);
             if (key != alac::KEY_IRREGULAR) {
                 if (classes_out) classes_out[i] = key;
-                status[i] = alac::decode_regular<HostWave>(wv, dc, key, true, p, sizes[i], o, &frames_out[i]);
+                if (variant == -3)
+                    status[i] = alac::decode_regular<HostWave>(wv, dc, key, true, p, sizes[i], o, &frames_out[i]);
+                else
+                    status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH>(wv, dc, key, true, p, sizes[i], o,
+                                                                                    &frames_out[i]);
                 continue;
             }
         }
-        if ((variant == -1 || variant == -2) && dc.kb != 0) {
+        if (variant < 0 && dc.kb != 0) {
             /* split pipeline, as alacgpu.hip runs it: scan -> one lean phase per channel -> interleave */
             alac::ChanDesc cd[8];
             memset(cd, 0, sizeof(cd));
