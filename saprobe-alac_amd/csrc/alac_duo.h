@@ -77,18 +77,28 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
     const uint64_t pk_msk = bps == 4 ? 0xffffffffull : ((1ull << (8u * bps)) - 1ull);
     const bool merge_any = DO_B && LAST && wv.any(sb != 0);
 
-    /* A: residuals of chunk c (DynDecomp, golomb.go:167-247) */
+    /* A: residuals of chunk c (DynDecomp, golomb.go:167-247). Whole chunks run as two straight-line groups of four
+     * steps (the bitstream ring is topped up once per group, 4 steps ahead of need). */
+    uint32_t ns_live = s.err == 0 ? ns : 0u;
+    uint32_t on_mask = (uint32_t)((int32_t)(0u - ns_live) >> 31); /* 0 < ns_live */
     auto golomb_chunk = [&](uint32_t c) {
         const uint32_t buf = c & 1u;
+        if ((c + 1u) * CH <= n_it) {
+#pragma nounroll
+            for (uint32_t g = 0; g < CH; g += 4u) {
+                s.rd.tick(wv);
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j)
+                    wv.rq_write(buf, g + j, gol_step(wv, bits, s, size, kb, wb, chan_bits, c * CH + g + j, ns, ns_live, on_mask));
+            }
+            return;
+        }
 #pragma nounroll
         for (uint32_t j = 0; j < CH; ++j) {
             const uint32_t i = c * CH + j;
             if (i >= n_it) break;
-            if ((i & 3u) == 0) s.rd.tick(wv); /* scalar test: bitstream ring refill, 4 steps ahead of need */
-            GolTent t;
-            gol_tentative(s, kb, i, ns, t);
-            const int32_t del = gol_commit(wv, bits, s, size, kb, wb, chan_bits, i, ns, t);
-            wv.rq_write(buf, j, del);
+            if ((i & 3u) == 0) s.rd.tick(wv);
+            wv.rq_write(buf, j, gol_step(wv, bits, s, size, kb, wb, chan_bits, i, ns, ns_live, on_mask));
         }
     };
     /* B: sample i is reconstructed: history; then the U hand-off tile, or unmix / shift merge / PCM.
@@ -144,7 +154,6 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             /* a lane that is not `on` appended nothing: clear what the OR left above its valid bytes */
             pk_acc &= pk_n ? ((1ull << (8u * pk_n)) - 1ull) : 0ull;
         }
-        wv.st_step(); /* collective of wave B */
     };
     /* B: samples of chunk c (UnpcBlock, predictor.go:45-684): out[0] = residual, warm-up up to na (:53-79),
      * copy (0) / delta (31) modes, then the adaptive taps */
@@ -175,6 +184,9 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
                     put(c * CH + g + j,
                         predict_narrow<NR, GEN, WRAP>(coef, hb, na, dv[j], den_shift, den_half, rnd_neg, chan_shift), uv[j],
                         sv[j]);
+                /* collective of wave B, once per group: a lane row holds 64 dwords, a flush takes 32, and a group
+                 * adds at most 8 steps x 2 dwords */
+                if (LAST) wv.st_step();
             }
             return;
         }
@@ -188,6 +200,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             else if (i <= na || (GEN && na == 31)) o = sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
             else o = predict_narrow<NR, GEN, WRAP>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
             put(i, o, CPE ? *wv.u_row(i) : 0, merge_any ? bits.window(shift_pos + i * sstep) : 0ull);
+            if (LAST) wv.st_step();
         }
     };
 

@@ -49,6 +49,10 @@
 /* unsigned a - b, 0 when b > a: v_sub_u32 ... clamp on the GPU */
 #define ALAC_SUBSAT(a, b) ((a) > (b) ? (a) - (b) : 0u)
 #endif
+#ifndef ALAC_CLAMP01
+/* 0 for x <= 0, 1 for x >= 1: one v_med3_i32 on the GPU */
+#define ALAC_CLAMP01(x) ((x) > 0 ? 1 : 0)
+#endif
 #ifndef ALAC_MULU24
 /* exact when both operands fit 24-bit unsigned: v_mul_u32_u24 / v_mad_u32_u24 on the GPU */
 #define ALAC_MULU24(a, b) ((uint32_t)(a) * (uint32_t)(b))
@@ -190,6 +194,15 @@ struct RingRd {
             fprintf(stderr, "ring mismatch at dword %u (fill %u widx %u limit %u pend %d)\n", ni + 2u, fill, widx, limit, (int)pend);
 #endif
     }
+    /* slide() without a compare: the move (0 or 1 dwords) becomes a bit mask */
+    ALAC_DEV void slide_mask(W& wv, uint32_t pos) {
+        const uint32_t ni = (pos + bias) >> 5;
+        const uint32_t cm = 0u - (ni - widx);
+        w0 = (w1 & cm) | (w0 & ~cm);
+        w1 = (w2 & cm) | (w1 & ~cm);
+        widx = ni;
+        w2 = wv.ring_read((ni + 2u) & 31u);
+    }
     /* every 4th step, wave-uniform */
     ALAC_DEV void tick(W& wv) {
         if (pend) commit(wv);
@@ -285,6 +298,58 @@ ALAC_DEV int32_t golomb_slow(const Bits& bits, RegLane<W>& s, uint32_t size, uin
 }
 
 /*
+ * One residual (DynDecomp, golomb.go:167-247), the form the entropy wave of alac_duo.h runs: a lone wave pays for
+ * EVERY instruction it issues (scalar ones and branches included, ~4-5 cycles each) and a v_cmp / v_cndmask pair
+ * costs ~17, so the step is written as plain integer arithmetic on bit masks: no compare, no select and no
+ * exec-mask juggling on the common path; the one branch left is the rare part (golomb_slow).
+ * ns_live: the lane's sample count, 0 once the lane has failed (i >= ns_live: a dead step, nothing moves).
+ * on_mask: ~0 when i < ns_live, carried from the previous step (updated here for step i+1).
+ */
+template <class W>
+ALAC_DEV int32_t gol_step(W& wv, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
+                          uint32_t chan_bits, uint32_t i, uint32_t ns, uint32_t& ns_live, uint32_t& on_mask) {
+    const uint32_t k = umin(31u - clz32((s.mean >> 9) + 3u), kb); /* 1..23 */
+    const uint32_t w = s.rd.window(s.pos);
+    const uint32_t pre = clz32(~w);
+    const uint32_t v = (w << ((pre + 1u) & 31u)) >> (32u - k);
+    const uint32_t vm1 = ALAC_SUBSAT(v, 1u);           /* v >= 2: value v - 1 and k bits; else 0 and k - 1 bits */
+    const uint32_t n = (pre << k) - pre + vm1;          /* pre * (2^k - 1) + ... */
+    const uint32_t nd = n + s.zmode;
+    const uint32_t mean2 = s.pb * nd + s.mean - ((s.pb * s.mean) >> 9); /* golomb.go:215 */
+    /* masks: lane decodes a code in this step (alive, not inside a zero run) */
+    const uint32_t next_on = (uint32_t)((int32_t)(i + 1u - ns_live) >> 31); /* i + 1 < ns_live (both < 2^31) */
+    const uint32_t norun = (uint32_t)((int32_t)(s.zrem - 1u) >> 31);        /* zrem == 0 (zrem <= 65535) */
+    const uint32_t okm = on_mask & norun;
+    /* rare cases, as nonzero-means-true flags: overrun (golomb.go:168), escape code (:184), n > 0xffff (:216),
+     * start of a zero run (:223: mean * 4 < 512 with a sample left; mean2 < 2^25 here, the shift cannot wrap) */
+    const uint32_t rare = (ALAC_SUBSAT(s.pos + 1u, s.max_pos) | ((pre + 7u) >> 4) | (n >> 16) |
+                           (ALAC_SUBSAT(128u, mean2) & next_on)) & okm;
+    const uint32_t hm = (nd + 1u) >> 1; /* golomb.go:206-209 */
+    const uint32_t sg = 0u - (nd & 1u);
+    int32_t del = (int32_t)(((hm ^ sg) - sg) & norun);
+    const uint32_t o_pos = s.pos, o_mean = s.mean, o_zmode = s.zmode, o_zrem = s.zrem;
+    s.pos = o_pos + ((pre + k + umin(vm1, 1u)) & okm); /* prefix + 1, then k bits (v >= 2) or k - 1 */
+    s.mean = (mean2 & okm) | (o_mean & ~okm);
+    s.zmode = o_zmode & ~okm;
+    s.zrem = ALAC_SUBSAT(o_zrem, 1u);
+    on_mask = next_on;
+    if (wv.any(rare != 0u)) {
+        if (rare != 0u) {
+            s.pos = o_pos;
+            s.mean = o_mean;
+            s.zmode = o_zmode;
+            s.zrem = o_zrem;
+            del = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns);
+            s.rd.reseek(wv, s.pos);
+            ns_live = s.err ? 0u : ns_live;
+            on_mask = (uint32_t)((int32_t)(i + 1u - ns_live) >> 31);
+        }
+    }
+    s.rd.slide_mask(wv, s.pos);
+    return del;
+}
+
+/*
  * One channel of a regular element, all lanes in lock step. NA = this channel's predictor order (wave-uniform).
  * LAST: this channel completes the frame (V of a pair, or the mono channel): unmix and emit PCM.
  */
@@ -341,9 +406,9 @@ ALAC_DEV int32_t gol_commit(W& wv, const Bits& bits, RegLane<W>& s, uint32_t siz
 
 /* ---- predictor step for i > na (UnpcBlock, predictor.go:99-684), chanBits <= 23 ---------------------------------
  * hb[j] = out[i-1-j] ^ BIAS (sign-biased history: |a - b| of biased values is one unsigned sad). Taps walked from
- * the highest down. The adaptation is sign-normalised: D0 = |del| shrinks (saturating at 0) by t_j = (na-j) *
- * ((|d_j| + rnd) >> denShift) tap after tap and tap j adapts while something of D0 is left. chanBits <= 23 keeps
- * q < 2^23 and t_j < 2^27: nothing wraps, which is what makes this equal to the reference's signed countdown.
+ * the highest down. The adaptation is sign-normalised: D0 = |del| shrinks by t_j = (na-j) * ((|d_j| + rnd) >>
+ * denShift) tap after tap and tap j adapts while something of D0 is left. chanBits <= 23 keeps q < 2^23 and
+ * t_j < 2^27: nothing wraps, which is what makes this equal to the reference's signed countdown.
  * GEN: the wave-uniform order na on NR = 16 register taps; WRAP: int16 coefficients (predictor.go:664,675). */
 template <int NR, bool GEN, bool WRAP>
 ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1], uint32_t na, int32_t del,
@@ -362,7 +427,9 @@ ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1
     /* delta_j = sign(del) * -sign(d_j) as (sd ^ nmask) + pm: identity for del < 0, negation otherwise */
     const uint32_t nmask = ~sgnm;
     const uint32_t pm = 1u + sgnm;
-    uint32_t rem = ((uint32_t)del ^ sgnm) - sgnm;         /* D0 = |del|: what is left of it after the taps above */
+    /* D0 = |del|: what is left of it after the taps above. Signed and never wrapping: the taps take at most
+     * sum(na - j) * 2^23 = 136 * 2^23 < 2^31 away from a value >= 0 */
+    int32_t rem = (int32_t)(((uint32_t)del ^ sgnm) - sgnm);
     int32_t dot = 0;
 #pragma unroll
     for (int j = NR - 1; j >= 0; --j) {
@@ -372,10 +439,10 @@ ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1
         const int32_t sd = ALAC_SIGN(d);
         const int32_t delta = (int32_t)(((uint32_t)sd ^ nmask) + pm);
         const uint32_t q = ALAC_SAD(topb, hb[j], rnd) >> den_shift;
-        const int32_t go = (int32_t)umin(rem, 1u); /* tap j adapts while the budget is not used up */
+        const int32_t go = ALAC_CLAMP01(rem); /* tap j adapts while the budget is not used up */
         const int32_t cj = coef[j] + ALAC_MUL24(delta, go);
         coef[j] = WRAP ? (int32_t)(int16_t)cj : cj; /* predictor.go:664,675 */
-        rem = ALAC_SUBSAT(rem, ALAC_MULU24(q, na - (uint32_t)j));
+        rem -= ALAC_MUL24((int32_t)q, (int32_t)(na - (uint32_t)j));
     }
     const int32_t acc = den_half - dot;
     return sext_cs(del + (int32_t)(topb ^ BIAS) + (acc >> den_shift), chan_shift);

@@ -34,6 +34,12 @@ __device__ __forceinline__ int32_t alac_sign_med3(int32_t x) {
     return r;
 }
 #define ALAC_SIGN(x) alac_sign_med3(x)
+__device__ __forceinline__ int32_t alac_clamp01_med3(int32_t x) {
+    int32_t r;
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(r) : "v"(x));
+    return r;
+}
+#define ALAC_CLAMP01(x) alac_clamp01_med3(x)
 #define ALAC_SUBSAT(a, b) __builtin_elementwise_sub_sat((uint32_t)(a), (uint32_t)(b))
 #define ALAC_MULU24(a, b) __umul24((unsigned)(a), (unsigned)(b))
 #define ALAC_PICK(dst, src) asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(src))
