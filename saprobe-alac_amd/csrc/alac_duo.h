@@ -41,8 +41,9 @@ enum { ROLE_A = 0, ROLE_B = 1, ROLE_BOTH = 2 };
 /*
  * One channel of a regular element. s: the lane's Golomb + reader state (role A). NA: this channel's predictor
  * order (role B; wave-uniform), 0 = the general form for na_rt in {0..16, 31} on 16 register taps.
+ * F16: 16-bit PCM of a pair (one dword per frame): the writer is compiled without the other widths' selects.
  */
-template <class W, int NA, int OUT, int ROLE>
+template <class W, int NA, int OUT, int ROLE, bool F16>
 ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
                         uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
                         uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb) {
@@ -75,7 +76,8 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
     uint32_t pk_n = 0;
     const uint32_t bps = cfg.bps;
     const uint64_t pk_msk = bps == 4 ? 0xffffffffull : ((1ull << (8u * bps)) - 1ull);
-    const bool merge_any = DO_B && LAST && wv.any(sb != 0);
+    const bool merge_any = DO_B && LAST && !F16 && wv.any(sb != 0);
+    const uint32_t nzm = mix_res != 0 ? 0xffffffffu : 0u; /* per lane: the pair is matrixed (matrix.go:34) */
 
     /* A: residuals of chunk c (DynDecomp, golomb.go:167-247). Whole chunks run as two straight-line groups of four
      * steps (the bitstream ring is topped up once per group, 4 steps ahead of need). */
@@ -114,14 +116,14 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
         const bool on = i < ns;
         int32_t l = o, r = 0;
         if (CPE) {
+            /* matrix.go:40-41 (mixRes != 0) and :50-51 (plain copy) in one branch-free form */
             const int32_t vv = o;
-            if (mix_res != 0) { /* matrix.go:40-41 */
-                l = u + vv - (ALAC_MUL24(mix_res, vv) >> mix_sh);
-                r = l - vv;
-            } else {
-                l = u;
-                r = vv;
-            }
+            l = u + (int32_t)((uint32_t)vv & nzm) - (ALAC_MUL24(mix_res, vv) >> mix_sh);
+            r = (int32_t)((((uint32_t)(l - vv)) & nzm) | ((uint32_t)vv & ~nzm));
+        }
+        if (F16) {
+            wv.st_push_if(((uint32_t)l & 0xffffu) | ((uint32_t)r << 16), on);
+            return;
         }
         if (cfg.bit_depth == 20) { /* matrix.go:77-78, 237 */
             l = (int32_t)((uint32_t)l << 4);
@@ -133,9 +135,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             l = (int32_t)((uint32_t)l << sb) | (int32_t)sh_l;
             r = (int32_t)((uint32_t)r << sb) | (int32_t)sh_r;
         }
-        if (bps == 2 && CPE) {
-            wv.st_push_if(((uint32_t)l & 0xffffu) | ((uint32_t)r << 16), on);
-        } else {
+        {
             /* generic widths: append bps bytes per sample, emit a dword whenever four are ready (all selects) */
             pk_acc |= ((uint64_t)(uint32_t)l & pk_msk) << (8u * pk_n);
             pk_n += on ? bps : 0u;
@@ -182,7 +182,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
 #pragma unroll
                 for (uint32_t j = 0; j < UN; ++j)
                     put(c * CH + g + j,
-                        predict_narrow<NR, GEN, WRAP>(coef, hb, na, dv[j], den_shift, den_half, rnd_neg, chan_shift), uv[j],
+                        predict_narrow<NR, GEN, WRAP, true>(coef, hb, na, dv[j], den_shift, den_half, rnd_neg, chan_shift), uv[j],
                         sv[j]);
                 /* collective of wave B, once per group: a lane row holds 64 dwords, a flush takes 32, and a group
                  * adds at most 8 steps x 2 dwords */
@@ -198,7 +198,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             int32_t o;
             if (i == 0 || (GEN && na == 0)) o = del;
             else if (i <= na || (GEN && na == 31)) o = sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
-            else o = predict_narrow<NR, GEN, WRAP>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
+            else o = predict_narrow<NR, GEN, WRAP, true>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
             put(i, o, CPE ? *wv.u_row(i) : 0, merge_any ? bits.window(shift_pos + i * sstep) : 0ull);
             if (LAST) wv.st_step();
         }
@@ -229,18 +229,18 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
 }
 
 /* the order switch is scalar: NA is wave-uniform by construction of the waves. Role A never looks at the order. */
-template <class W, int OUT, int ROLE>
+template <class W, int OUT, int ROLE, bool F16>
 ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size,
                            uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
                            int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb) {
 #define ALAC_DUO_CASE(N)                                                                                              \
     case N:                                                                                                           \
-        duo_phase<W, N, OUT, ROLE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, \
-                                   na, shift_pos, sb);                                                                \
+        duo_phase<W, N, OUT, ROLE, F16>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res,    \
+                                        mix_sh, na, shift_pos, sb);                                                  \
         break;
     if (ROLE == ROLE_A) {
-        duo_phase<W, 0, OUT, ROLE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na,
-                                   shift_pos, sb);
+        duo_phase<W, 0, OUT, ROLE, F16>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh,
+                                        na, shift_pos, sb);
         return;
     }
     switch (na) {
@@ -261,8 +261,8 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bi
         ALAC_DUO_CASE(15)
         ALAC_DUO_CASE(16)
         default:
-            duo_phase<W, 0, OUT, ROLE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh,
-                                       na, shift_pos, sb);
+            duo_phase<W, 0, OUT, ROLE, F16>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res,
+                                            mix_sh, na, shift_pos, sb);
             break;
     }
 #undef ALAC_DUO_CASE
@@ -319,8 +319,8 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     s.zrem = 0;
     s.pb = (cfg.pb * ((hu >> 5) & 7u)) / 4u; /* decoder.go:299 */
     if (DO_A) s.rd.start(wv, live ? s.pos : 0u);
-    if (cpe) duo_phase_na<W, OUT_UTILE, ROLE>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
-    else duo_phase_na<W, OUT_MONO, ROLE>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
+    if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
+    else duo_phase_na<W, OUT_MONO, ROLE, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
     uint32_t err_chan = 0;
     /* ---- V ---- */
     if (cpe) {
@@ -332,7 +332,10 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
         s.zrem = 0;
         s.pb = (cfg.pb * ((hv >> 5) & 7u)) / 4u;
         if (DO_A) s.rd.start(wv, (live && s.err == 0) ? s.pos : 0u);
-        duo_phase_na<W, OUT_STEREO, ROLE>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+        if (cfg.bit_depth == 16)
+            duo_phase_na<W, OUT_STEREO, ROLE, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+        else
+            duo_phase_na<W, OUT_STEREO, ROLE, false>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
         if (err_u == 0 && s.err != 0) err_chan = 1;
     }
     if (DO_B && live) (void)wv.st_finish();

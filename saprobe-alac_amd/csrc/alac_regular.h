@@ -53,6 +53,15 @@
 /* 0 for x <= 0, 1 for x >= 1: one v_med3_i32 on the GPU */
 #define ALAC_CLAMP01(x) ((x) > 0 ? 1 : 0)
 #endif
+#ifndef ALAC_XAD
+/* (a ^ b) + c: one v_xad_u32 on the GPU */
+#define ALAC_XAD(a, b, c) ((((uint32_t)(a)) ^ ((uint32_t)(b))) + (uint32_t)(c))
+#endif
+#ifndef ALAC_MSUB24
+/* acc - a * c for 24-bit a and a small wave-uniform c: one v_mad_i32_i24 with -c as its scalar operand on the GPU
+ * (written as a product the compiler turns multiplications by 2, 4, 8 into two shifts and a subtraction) */
+#define ALAC_MSUB24(acc, a, c) ((int32_t)(acc) - (int32_t)(a) * (int32_t)(c))
+#endif
 #ifndef ALAC_MULU24
 /* exact when both operands fit 24-bit unsigned: v_mul_u32_u24 / v_mad_u32_u24 on the GPU */
 #define ALAC_MULU24(a, b) ((uint32_t)(a) * (uint32_t)(b))
@@ -410,7 +419,7 @@ ALAC_DEV int32_t gol_commit(W& wv, const Bits& bits, RegLane<W>& s, uint32_t siz
  * denShift) tap after tap and tap j adapts while something of D0 is left. chanBits <= 23 keeps q < 2^23 and
  * t_j < 2^27: nothing wraps, which is what makes this equal to the reference's signed countdown.
  * GEN: the wave-uniform order na on NR = 16 register taps; WRAP: int16 coefficients (predictor.go:664,675). */
-template <int NR, bool GEN, bool WRAP>
+template <int NR, bool GEN, bool WRAP, bool CB_POS = false>
 ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1], uint32_t na, int32_t del,
                                 uint32_t den_shift, int32_t den_half, uint32_t rnd_neg, uint32_t chan_shift) {
     constexpr uint32_t BIAS = 0x80000000u;
@@ -437,15 +446,17 @@ ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1
         const int32_t d = (int32_t)(topb - hb[j]); /* top - out[i-1-j]; the bias cancels */
         dot += ALAC_MUL24(coef[j], d);             /* uses coef[j] before its update */
         const int32_t sd = ALAC_SIGN(d);
-        const int32_t delta = (int32_t)(((uint32_t)sd ^ nmask) + pm);
+        const int32_t delta = (int32_t)ALAC_XAD(sd, nmask, pm);
         const uint32_t q = ALAC_SAD(topb, hb[j], rnd) >> den_shift;
         const int32_t go = ALAC_CLAMP01(rem); /* tap j adapts while the budget is not used up */
         const int32_t cj = coef[j] + ALAC_MUL24(delta, go);
         coef[j] = WRAP ? (int32_t)(int16_t)cj : cj; /* predictor.go:664,675 */
-        rem -= ALAC_MUL24((int32_t)q, (int32_t)(na - (uint32_t)j));
+        rem = ALAC_MSUB24(rem, q, na - (uint32_t)j);
     }
     const int32_t acc = den_half - dot;
-    return sext_cs(del + (int32_t)(topb ^ BIAS) + (acc >> den_shift), chan_shift);
+    const int32_t o = del + (int32_t)(topb ^ BIAS) + (acc >> den_shift);
+    /* CB_POS: the caller knows chanBits >= 1, so the shift count is <= 31 and sext_cs' guard for 32 is not needed */
+    return CB_POS ? (int32_t)((uint32_t)o << chan_shift) >> chan_shift : sext_cs(o, chan_shift);
 }
 
 /* what a phase does with the reconstructed samples */

@@ -40,6 +40,18 @@ __device__ __forceinline__ int32_t alac_clamp01_med3(int32_t x) {
     return r;
 }
 #define ALAC_CLAMP01(x) alac_clamp01_med3(x)
+__device__ __forceinline__ uint32_t alac_xad(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#define ALAC_XAD(a, b, c) alac_xad((uint32_t)(a), (uint32_t)(b), (uint32_t)(c))
+__device__ __forceinline__ int32_t alac_msub24(int32_t acc, int32_t a, int32_t negc) {
+    int32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(negc), "v"(acc));
+    return r;
+}
+#define ALAC_MSUB24(acc, a, c) alac_msub24((int32_t)(acc), (int32_t)(a), -(int32_t)(c))
 #define ALAC_SUBSAT(a, b) __builtin_elementwise_sub_sat((uint32_t)(a), (uint32_t)(b))
 #define ALAC_MULU24(a, b) __umul24((unsigned)(a), (unsigned)(b))
 #define ALAC_PICK(dst, src) asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(src))
