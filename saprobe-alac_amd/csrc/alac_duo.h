@@ -28,6 +28,9 @@
 
 #include "alac_regular.h"
 
+#ifndef ALAC_DUO_UN8_MAX
+#define ALAC_DUO_UN8_MAX 8 /* longest predictor whose steady-state chunk is unrolled whole */
+#endif
 #ifndef ALAC_DUO_STAMP
 /* profiling build only (-DALAC_DUO_PROF in alacgpu.hip): time stamps around the parts of an iteration */
 #define ALAC_DUO_STAMP(k)
@@ -166,7 +169,8 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             /* steady state, a whole chunk: straight-line code; residuals (LDS), U samples and shift values
              * (HBM/L2) are all requested up front and their latency hides behind the taps of the first steps;
              * the history shift becomes register renaming across the unrolled steps */
-            constexpr uint32_t UN = NR <= 8 ? CH : CH / 2u; /* long predictors: half chunks, or registers run out */
+            /* long predictors and the wide writers (64-bit shift windows): half chunks, or registers run out */
+            constexpr uint32_t UN = (NR <= ALAC_DUO_UN8_MAX && (F16 || !LAST)) ? CH : CH / 2u;
 #pragma nounroll
             for (uint32_t g = 0; g < CH; g += UN) {
                 int32_t dv[UN], uv[UN];

@@ -53,6 +53,11 @@
 /* 0 for x <= 0, 1 for x >= 1: one v_med3_i32 on the GPU */
 #define ALAC_CLAMP01(x) ((x) > 0 ? 1 : 0)
 #endif
+#ifndef ALAC_MAD24
+/* a * b + c for 24-bit a, b: one v_mad_i32_i24 on the GPU, opaque to the optimiser (a sum of such products written
+ * plainly is re-associated into multiplies and a tree of adds: more instructions for latency nobody is waiting on) */
+#define ALAC_MAD24(a, b, c) ((int32_t)(a) * (int32_t)(b) + (int32_t)(c))
+#endif
 #ifndef ALAC_XAD
 /* (a ^ b) + c: one v_xad_u32 on the GPU */
 #define ALAC_XAD(a, b, c) ((((uint32_t)(a)) ^ ((uint32_t)(b))) + (uint32_t)(c))
@@ -431,29 +436,27 @@ ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1
     }
     /* no compares on the hot path (a v_cmp / v_cndmask pair costs a lone wave ~17 cycles, plain ALU ops ~5):
      * everything that depends on the sign of the residual is derived from its sign mask */
-    const uint32_t sgnm = (uint32_t)(del >> 31);          /* ~0 for del < 0 */
+    const uint32_t sgnm = (uint32_t)(del >> 31); /* ~0 for del < 0 */
+    const uint32_t nsg = (uint32_t)del >> 31;    /* 1 for del < 0 */
     const uint32_t rnd = rnd_neg & sgnm;
-    /* delta_j = sign(del) * -sign(d_j) as (sd ^ nmask) + pm: identity for del < 0, negation otherwise */
-    const uint32_t nmask = ~sgnm;
-    const uint32_t pm = 1u + sgnm;
     /* D0 = |del|: what is left of it after the taps above. Signed and never wrapping: the taps take at most
      * sum(na - j) * 2^23 = 136 * 2^23 < 2^31 away from a value >= 0 */
-    int32_t rem = (int32_t)(((uint32_t)del ^ sgnm) - sgnm);
-    int32_t dot = 0;
+    int32_t rem = (int32_t)(((uint32_t)del ^ sgnm) + nsg);
+    /* den_half - sum coef_j * (top - h_j), as one multiply-add chain over e_j = h_j - top */
+    int32_t acc = den_half;
 #pragma unroll
     for (int j = NR - 1; j >= 0; --j) {
         if (GEN && (uint32_t)j >= na) continue; /* scalar branch: taps the order does not have */
-        const int32_t d = (int32_t)(topb - hb[j]); /* top - out[i-1-j]; the bias cancels */
-        dot += ALAC_MUL24(coef[j], d);             /* uses coef[j] before its update */
-        const int32_t sd = ALAC_SIGN(d);
-        const int32_t delta = (int32_t)ALAC_XAD(sd, nmask, pm);
+        const int32_t e = (int32_t)(hb[j] - topb); /* out[i-1-j] - top; the bias cancels */
+        acc = ALAC_MAD24(coef[j], e, acc);         /* uses coef[j] before its update */
+        /* coefficient step sign(del) * -sign(top - h_j) = sign(del) * sign(e): (sign(e) ^ sgnm) + nsg */
+        const int32_t delta = (int32_t)ALAC_XAD(ALAC_SIGN(e), sgnm, nsg);
         const uint32_t q = ALAC_SAD(topb, hb[j], rnd) >> den_shift;
         const int32_t go = ALAC_CLAMP01(rem); /* tap j adapts while the budget is not used up */
-        const int32_t cj = coef[j] + ALAC_MUL24(delta, go);
+        const int32_t cj = ALAC_MAD24(delta, go, coef[j]);
         coef[j] = WRAP ? (int32_t)(int16_t)cj : cj; /* predictor.go:664,675 */
         rem = ALAC_MSUB24(rem, q, na - (uint32_t)j);
     }
-    const int32_t acc = den_half - dot;
     const int32_t o = del + (int32_t)(topb ^ BIAS) + (acc >> den_shift);
     /* CB_POS: the caller knows chanBits >= 1, so the shift count is <= 31 and sext_cs' guard for 32 is not needed */
     return CB_POS ? (int32_t)((uint32_t)o << chan_shift) >> chan_shift : sext_cs(o, chan_shift);

@@ -46,6 +46,12 @@ __device__ __forceinline__ uint32_t alac_xad(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 #define ALAC_XAD(a, b, c) alac_xad((uint32_t)(a), (uint32_t)(b), (uint32_t)(c))
+__device__ __forceinline__ int32_t alac_mad24(int32_t a, int32_t b, int32_t c) {
+    int32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#define ALAC_MAD24(a, b, c) alac_mad24((int32_t)(a), (int32_t)(b), (int32_t)(c))
 __device__ __forceinline__ int32_t alac_msub24(int32_t acc, int32_t a, int32_t negc) {
     int32_t r;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(negc), "v"(acc));
@@ -105,6 +111,7 @@ struct Plan {
     uint32_t list_key[kKeys];
     uint32_t list_wave0[kKeys]; /* first block id */
     uint32_t total_waves;
+    uint32_t irr_waves; /* waves of the irregular keys (>= 1024): they come first */
 };
 
 /* LDS of the decode kernel (one wave per workgroup). Referenced by name, never through a generic pointer, so
@@ -117,6 +124,10 @@ constexpr uint32_t kQ = alac::DUO_CHUNK;
 __shared__ int32_t s_rq[2 * kQ * kWave];
 __shared__ int32_t s_sq[2 * kQ * kWave];
 
+/* U hand-off tile of one wave: frame_length rows of 64 cells and one spare row (the single-wave decoders read one
+ * row ahead) */
+__host__ __device__ inline size_t u_tile_cells(uint32_t frame_length) { return ((size_t)frame_length + 1u) * kWave; }
+
 /* ---- gfx950 wave policy for alac::decode_wave --------------------------------------------------------- */
 struct GpuWave {
     int32_t* u_tile;           /* HBM: this lane's column of the wave's U hand-off tile */
@@ -124,7 +135,6 @@ struct GpuWave {
     uint8_t* my_out;
     uint32_t lane, wcnt, flushed;
     uint32_t ppw;              /* packets (= live lanes) per wave; also the row stride of the HBM tiles */
-    uint32_t u_stride;         /* ppw, or 0 for lanes >= ppw: they own one dummy cell behind the tile */
 #ifdef ALAC_DUO_PROF
     unsigned long long prof[4] = {0, 0, 0, 0}, prof_t = 0;
 #endif
@@ -208,7 +218,9 @@ struct GpuWave {
         __threadfence_block();
         __syncthreads();
     }
-    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * u_stride; }
+    /* rows of 64 cells whatever ppw is: a constant stride lets unrolled steps address their rows by immediate
+     * offsets from one base, and every lane (with or without a packet) owns a column */
+    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * kWave; }
     ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * ppw; }
 };
 
@@ -244,6 +256,7 @@ __global__ void __launch_bounds__(256) alac_plan(Plan* plan, uint32_t ppw) {
     if (threadIdx.x == 0) {
         uint32_t p = 0, w = 0, nk = 0;
         for (int k = (int)kKeys - 1; k >= 0; --k) {
+            if (k == 1023) plan->irr_waves = w;
             const uint32_t c = cnt[k];
             cnt[k] = p; /* becomes pkt_start */
             if (c) {
@@ -286,34 +299,28 @@ alac_scatter(const uint16_t* __restrict__ keys, uint32_t n, Plan* plan, uint32_t
     if (i < n && key != alac::TASK_NONE) perm[base[key] + local] = i;
 }
 
-/* two waves per SIMD (four workgroups per CU) is what the wave pair is built for: cap the register budget there */
-__global__ void __launch_bounds__(2 * kWave, 2)
-alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
-            const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
-            uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
-            int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g,
-            uint32_t ppw, alac::ChanDesc* __restrict__ cd, alac::PktDesc* __restrict__ pd) {
-
+/* Irregular packets (keys >= 1024; they own the first plan->irr_waves wave slots): one wavefront per 64 packets.
+ * With a usable KB they are scanned (status, frame count, channel descriptors: split pipeline step 1, PCM comes
+ * from the later kernels); with KB == 0 the whole-packet decoder takes them. */
+__global__ void __launch_bounds__(kWave)
+alac_scan(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+          const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+          uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
+          int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g,
+          uint32_t ppw, alac::ChanDesc* __restrict__ cd, alac::PktDesc* __restrict__ pd) {
     const uint32_t b = blockIdx.x;
-    if (b >= plan->total_waves) return;
-    /* which key owns block b: last list entry whose first wave is <= b (a handful of entries) */
+    if (b >= plan->irr_waves) return;
     uint32_t e = 0;
     for (uint32_t t = 1; t < plan->nk; ++t)
         if (plan->list_wave0[t] <= b) e = t;
     const uint32_t key = plan->list_key[e];
-    /* two waves per workgroup, the same 64 packets in both (alac_duo.h): wave 0 = role A, wave 1 = role B */
-    const uint32_t lane = threadIdx.x & (kWave - 1u);
-    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x;
     const uint32_t idx = (b - plan->list_wave0[e]) * ppw + lane;
     const bool live = lane < ppw && idx < plan->count[key];
     const uint32_t pkt = live ? perm[plan->pkt_start[key] + idx] : 0u;
 
     GpuWave wv;
-    /* U tile: frame_length rows of ppw cells, then 64 dummy cells for the lanes that hold no packet (the lean
-     * decoder stores without a branch, so every lane needs a cell of its own) */
-    const size_t tile_cells = (size_t)cfg.frame_length * ppw + kWave;
-    wv.u_stride = lane < ppw ? ppw : 0u;
-    wv.u_tile = scratch_u + (size_t)b * tile_cells + (lane < ppw ? lane : (size_t)cfg.frame_length * ppw + lane);
+    wv.u_tile = scratch_u + (size_t)b * u_tile_cells(cfg.frame_length) + lane;
     wv.g_tile = scratch_g + (size_t)b * kFallbackSlots * ppw + lane;
     wv.ppw = ppw;
     wv.my_out = nullptr;
@@ -325,36 +332,69 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     uint8_t* o = out + (size_t)pkt * out_stride;
     uint32_t frames = 0;
     int32_t st;
-    /* the key is wave-uniform (one key per block): scalar branches pick the variant */
     const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
-    if (ukey < 1024u) {
-        if (role != 0u) {
-            (void)alac::decode_regular_duo<GpuWave, alac::ROLE_B>(wv, cfg, ukey, live, p, size, o, &frames);
-#ifdef ALAC_DUO_PROF
-            if (lane == 0)
-                for (int k = 0; k < 4; ++k) atomicAdd(&g_duo_prof[8 + k], wv.prof[k]);
-#endif
-            return;
-        }
-        /* the entropy chain is the critical path of the pair: it issues whenever it can, the predictor wave
-         * (many independent instructions) fills the slots in between */
-        __builtin_amdgcn_s_setprio(3);
-        st = alac::decode_regular_duo<GpuWave, alac::ROLE_A>(wv, cfg, ukey, live, p, size, o, &frames);
+    if (ukey == kKeyScan)
+        st = alac::decode_wave<GpuWave, 16, true, true>(wv, cfg, live, p, size, o, &frames, cd + (size_t)pkt * 8u, pd + pkt);
+    else
+        st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, o, &frames);
+    if (live) {
+        frames_out[pkt] = frames;
+        status[pkt] = st;
+    }
+}
+
+/* Regular packets: a pair of wavefronts per 64 packets with the SAME key (alac_duo.h): wave 0 = role A (entropy),
+ * wave 1 = role B (predictor + PCM), lane = packet in both. Two waves per SIMD (four workgroups per CU) is what
+ * the pair is built for: the register budget is capped there. */
+__global__ void __launch_bounds__(2 * kWave, 2)
+alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+            const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+            uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
+            int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, uint32_t ppw) {
+    const uint32_t b = blockIdx.x + plan->irr_waves;
+    if (b >= plan->total_waves) return;
+    /* which key owns wave slot b: last list entry whose first wave is <= b (a handful of entries) */
+    uint32_t e = 0;
+    for (uint32_t t = 1; t < plan->nk; ++t)
+        if (plan->list_wave0[t] <= b) e = t;
+    const uint32_t key = plan->list_key[e];
+    const uint32_t lane = threadIdx.x & (kWave - 1u);
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t idx = (b - plan->list_wave0[e]) * ppw + lane;
+    const bool live = lane < ppw && idx < plan->count[key];
+    const uint32_t pkt = live ? perm[plan->pkt_start[key] + idx] : 0u;
+
+    GpuWave wv;
+    /* U tile: a column per lane (the decoders store without a branch, so lanes without a packet need cells too) */
+    wv.u_tile = scratch_u + (size_t)b * u_tile_cells(cfg.frame_length) + lane;
+    wv.g_tile = nullptr;
+    wv.ppw = ppw;
+    wv.my_out = nullptr;
+    wv.lane = lane;
+    wv.wcnt = wv.flushed = 0;
+
+    const uint8_t* p = blob + (live ? offsets[pkt] : offsets[0]);
+    const uint32_t size = live ? sizes[pkt] : 0u;
+    uint8_t* o = out + (size_t)pkt * out_stride;
+    uint32_t frames = 0;
+    /* the key is wave-uniform (one key per workgroup): scalar branches pick the variant */
+    const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+    if (role != 0u) {
+        (void)alac::decode_regular_duo<GpuWave, alac::ROLE_B>(wv, cfg, ukey, live, p, size, o, &frames);
 #ifdef ALAC_DUO_PROF
         if (lane == 0)
-            for (int k = 0; k < 4; ++k) atomicAdd(&g_duo_prof[k], wv.prof[k]);
+            for (int k = 0; k < 4; ++k) atomicAdd(&g_duo_prof[8 + k], wv.prof[k]);
 #endif
-    } else if (role != 0u) {
-        return; /* irregular packets: one wave walks them */
-#ifndef ALAC_EXP_NO_SCAN
-    } else if (ukey == kKeyScan) {
-        /* split pipeline, step 1: status, frame count and channel descriptors; PCM comes from alac_interleave */
-        st = alac::decode_wave<GpuWave, 16, true, true>(wv, cfg, live, p, size, o, &frames, cd + (size_t)pkt * 8u,
-                                                        pd + pkt);
-#endif
-    } else {
-        st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, o, &frames);
+        return;
     }
+    /* the entropy chain is the critical path of the pair: it issues whenever it can, the predictor wave (many
+     * independent instructions) fills the slots in between */
+    __builtin_amdgcn_s_setprio(3);
+    const int32_t st = alac::decode_regular_duo<GpuWave, alac::ROLE_A>(wv, cfg, ukey, live, p, size, o, &frames);
+#ifdef ALAC_DUO_PROF
+    if (lane == 0)
+        for (int k = 0; k < 4; ++k) atomicAdd(&g_duo_prof[k], wv.prof[k]);
+#endif
     if (live) {
         frames_out[pkt] = frames;
         status[pkt] = st;
@@ -405,7 +445,6 @@ alac_chan_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint6
     const uint32_t pkt = t >> 3, slot = t & 7u;
 
     GpuWave wv;
-    wv.u_stride = 0;
     wv.u_tile = nullptr;
     wv.g_tile = nullptr;
     wv.ppw = ppw;
@@ -465,9 +504,7 @@ alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     if (__ballot(live) == 0ull) return;
 
     GpuWave wv;
-    const size_t tile_cells = (size_t)cfg.frame_length * ppw + kWave;
-    wv.u_stride = lane < ppw ? ppw : 0u;
-    wv.u_tile = scratch_u + (size_t)b * tile_cells + (lane < ppw ? lane : (size_t)cfg.frame_length * ppw + lane);
+    wv.u_tile = scratch_u + (size_t)b * u_tile_cells(cfg.frame_length) + lane;
     wv.g_tile = scratch_g + (size_t)b * kFallbackSlots * ppw + lane;
     wv.ppw = ppw;
     wv.my_out = nullptr;
@@ -591,7 +628,7 @@ size_t row_stride_of(uint32_t frame_length) { return ((size_t)frame_length + 3u)
 int reserve_workspace(alacgpu_decoder* dec, size_t n, uint32_t ppw) {
     const size_t waves = max_waves(n, ppw);
     int rc;
-    if ((rc = dec->scratch_u.ensure(waves * ((size_t)dec->cfg.frame_length * ppw + kWave) * sizeof(int32_t)))) return rc;
+    if ((rc = dec->scratch_u.ensure(waves * u_tile_cells(dec->cfg.frame_length) * sizeof(int32_t)))) return rc;
     if ((rc = dec->scratch_g.ensure(waves * kFallbackSlots * ppw * sizeof(int32_t)))) return rc;
     if ((rc = dec->plan.ensure(sizeof(Plan)))) return rc;
     if ((rc = dec->cls.ensure((n ? n : 1) * sizeof(uint16_t)))) return rc;
@@ -631,13 +668,18 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
                        (uint32_t*)dec->perm.p);
     const uint32_t slot = (uint32_t)(dec->launches % kTimingSlots);
     HIP_TRY(hipEventRecord(dec->ev_start[slot], dec->stream));
-    hipLaunchKernelGGL(alac_decode, dim3((uint32_t)max_waves(n, ppw)), dim3(2 * kWave), 0, dec->stream, c, d_blob, d_offsets,
+    /* irregular packets first (usually a handful of waves, or none), then the wave pairs of the regular ones */
+    hipLaunchKernelGGL(alac_scan, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, d_offsets,
                        d_sizes, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride, d_frames,
                        d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw, (alac::ChanDesc*)dec->cd.p,
                        (alac::PktDesc*)dec->pd.p);
+    if (dec->cfg.num_channels <= 2 && dec->cfg.kb != 0)
+        hipLaunchKernelGGL(alac_decode, dim3((uint32_t)max_waves(n, ppw)), dim3(2 * kWave), 0, dec->stream, c, d_blob,
+                           d_offsets, d_sizes, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride,
+                           d_frames, d_status, (int32_t*)dec->scratch_u.p, ppw);
     HIP_TRY(hipGetLastError());
     if (dec->cfg.kb != 0) {
-        /* irregular packets were only scanned by alac_decode (status, frames, channel descriptors) */
+        /* irregular packets were only scanned by alac_scan (status, frames, channel descriptors) */
         const uint64_t rs = row_stride_of(dec->cfg.frame_length);
         const uint32_t bpp = (dec->cfg.frame_length + 255u) / 256u;
         if (dec->cfg.num_channels > 2) {
