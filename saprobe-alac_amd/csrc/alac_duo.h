@@ -45,13 +45,17 @@ enum { ROLE_A = 0, ROLE_B = 1, ROLE_BOTH = 2 };
  * One channel of a regular element. s: the lane's Golomb + reader state (role A). NA: this channel's predictor
  * order (role B; wave-uniform), 0 = the general form for na_rt in {0..16, 31} on 16 register taps.
  * F16: 16-bit PCM of a pair (one dword per frame): the writer is compiled without the other widths' selects.
+ * NARROW: chanBits <= 23 (predict_narrow), else the 32-bit literal form (predict_wide).
+ * mode (per lane) != 0: the delta pre-pass of decoder.go:307-309 runs on the residual stream first (split
+ * pipeline only: regular packets have mode 0).
  */
-template <class W, int NA, int OUT, int ROLE, bool F16>
+template <class W, int NA, int OUT, int ROLE, bool F16, bool NARROW>
 ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
                         uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
-                        uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb) {
+                        uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb, uint32_t mode) {
     constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
-    constexpr bool LAST = OUT == OUT_STEREO || OUT == OUT_MONO;
+    constexpr bool RAW = OUT == OUT_RAW;
+    constexpr bool LAST = OUT == OUT_STEREO || OUT == OUT_MONO || RAW; /* B stages what it reconstructs */
     constexpr bool CPE = OUT == OUT_STEREO;
     constexpr bool GEN = NA == 0;
     constexpr int NR = GEN ? 16 : NA;
@@ -79,7 +83,20 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
     uint32_t pk_n = 0;
     const uint32_t bps = cfg.bps;
     const uint64_t pk_msk = bps == 4 ? 0xffffffffull : ((1ull << (8u * bps)) - 1ull);
-    const bool merge_any = DO_B && LAST && !F16 && wv.any(sb != 0);
+    const bool merge_any = DO_B && LAST && !F16 && !RAW && wv.any(sb != 0);
+    /* decoder.go:307-309: UnpcBlock(numActive 31, denShift 0) over the residuals before the coefficient pass */
+    const bool mode_any = DO_B && wv.any(mode != 0);
+    int32_t dprev = 0;
+    auto prepass = [&](uint32_t idx, int32_t del) -> int32_t {
+        if (!mode_any) return del;
+        const int32_t dd = idx == 0 ? del : sext_cs(del + dprev, chan_shift);
+        dprev = mode != 0 ? dd : dprev;
+        return mode != 0 ? dd : del;
+    };
+    auto predict = [&](int32_t del) -> int32_t {
+        if (NARROW) return predict_narrow<NR, GEN, WRAP, !RAW>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
+        return predict_wide<NR, GEN, WRAP>(coef, hb, na, del, den_shift, den_half, chan_shift);
+    };
     const uint32_t nzm = mix_res != 0 ? 0xffffffffu : 0u; /* per lane: the pair is matrixed (matrix.go:34) */
 
     /* A: residuals of chunk c (DynDecomp, golomb.go:167-247). Whole chunks run as two straight-line groups of four
@@ -117,6 +134,10 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             return;
         }
         const bool on = i < ns;
+        if (RAW) {
+            wv.st_push_if((uint32_t)o, on); /* one int32 sample per step into the lane's row */
+            return;
+        }
         int32_t l = o, r = 0;
         if (CPE) {
             /* matrix.go:40-41 (mixRes != 0) and :50-51 (plain copy) in one branch-free form */
@@ -165,12 +186,12 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
         const bool simple = GEN && (na == 0 || na == 31);
         /* both shift values of a frame sit side by side (decoder.go:492-502): one window */
         const uint32_t sstep = (CPE ? 2u : 1u) * sb;
-        if (!simple && c * CH > na && (c + 1u) * CH <= n_it) {
+        if (!simple && !mode_any && c * CH > na && (c + 1u) * CH <= n_it) {
             /* steady state, a whole chunk: straight-line code; residuals (LDS), U samples and shift values
              * (HBM/L2) are all requested up front and their latency hides behind the taps of the first steps;
              * the history shift becomes register renaming across the unrolled steps */
             /* long predictors and the wide writers (64-bit shift windows): half chunks, or registers run out */
-            constexpr uint32_t UN = (NR <= ALAC_DUO_UN8_MAX && (F16 || !LAST)) ? CH : CH / 2u;
+            constexpr uint32_t UN = (NR <= ALAC_DUO_UN8_MAX && NARROW && (F16 || !LAST || RAW)) ? CH : CH / 2u;
 #pragma nounroll
             for (uint32_t g = 0; g < CH; g += UN) {
                 int32_t dv[UN], uv[UN];
@@ -185,9 +206,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
                 }
 #pragma unroll
                 for (uint32_t j = 0; j < UN; ++j)
-                    put(c * CH + g + j,
-                        predict_narrow<NR, GEN, WRAP, true>(coef, hb, na, dv[j], den_shift, den_half, rnd_neg, chan_shift), uv[j],
-                        sv[j]);
+                    put(c * CH + g + j, predict(dv[j]), uv[j], sv[j]);
                 /* collective of wave B, once per group: a lane row holds 64 dwords, a flush takes 32, and a group
                  * adds at most 8 steps x 2 dwords */
                 if (LAST) wv.st_step();
@@ -198,11 +217,11 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
         for (uint32_t j = 0; j < CH; ++j) {
             const uint32_t i = c * CH + j;
             if (i >= n_it) break;
-            const int32_t del = wv.rq_read(buf, j);
+            const int32_t del = prepass(i, wv.rq_read(buf, j));
             int32_t o;
             if (i == 0 || (GEN && na == 0)) o = del;
             else if (i <= na || (GEN && na == 31)) o = sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
-            else o = predict_narrow<NR, GEN, WRAP, true>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
+            else o = predict(del);
             put(i, o, CPE ? *wv.u_row(i) : 0, merge_any ? bits.window(shift_pos + i * sstep) : 0ull);
             if (LAST) wv.st_step();
         }
@@ -233,18 +252,18 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
 }
 
 /* the order switch is scalar: NA is wave-uniform by construction of the waves. Role A never looks at the order. */
-template <class W, int OUT, int ROLE, bool F16>
+template <class W, int OUT, int ROLE, bool F16, bool NARROW = true>
 ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size,
                            uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
-                           int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb) {
+                           int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb, uint32_t mode = 0u) {
 #define ALAC_DUO_CASE(N)                                                                                              \
     case N:                                                                                                           \
-        duo_phase<W, N, OUT, ROLE, F16>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res,    \
-                                        mix_sh, na, shift_pos, sb);                                                  \
+        duo_phase<W, N, OUT, ROLE, F16, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,      \
+                                                mix_res, mix_sh, na, shift_pos, sb, mode);                            \
         break;
     if (ROLE == ROLE_A) {
-        duo_phase<W, 0, OUT, ROLE, F16>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh,
-                                        na, shift_pos, sb);
+        duo_phase<W, 0, OUT, ROLE, F16, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res,
+                                                mix_sh, na, shift_pos, sb, mode);
         return;
     }
     switch (na) {
@@ -265,8 +284,8 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bi
         ALAC_DUO_CASE(15)
         ALAC_DUO_CASE(16)
         default:
-            duo_phase<W, 0, OUT, ROLE, F16>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res,
-                                            mix_sh, na, shift_pos, sb);
+            duo_phase<W, 0, OUT, ROLE, F16, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
+                                                    mix_res, mix_sh, na, shift_pos, sb, mode);
             break;
     }
 #undef ALAC_DUO_CASE

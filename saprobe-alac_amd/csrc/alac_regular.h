@@ -1,18 +1,20 @@
 /*
- * alac_regular.h — the lean wave decoder for REGULAR packets (the overwhelming majority of real streams).
+ * alac_regular.h — building blocks of the lean decoders: the packet classifier, the LDS-ring bit reader, the
+ * Golomb/Rice step and the adaptive predictor step.
  *
- * A packet is regular when classify_regular() accepts it: 16-bit, mono or stereo, its first tag is the one
- * element that covers the whole frame (SCE/LFE for 1 channel, CPE for 2), compressed, no shift bytes,
- * mode 0 on both channels, predictor orders in {4,5,6,8} (the reference's unrolled int32-coefficient
- * predictors, predictor.go:81-93), header inside the packet. Everything else takes decode_wave (alac_wave.h),
- * which decodes any packet. The two produce identical bytes and status words; which one runs is a speed
- * choice made per packet by the classifier, and waves are built from packets with the same (numU, numV).
+ * A packet is REGULAR when classify_regular() accepts it: mono or stereo, its first tag is the one element that
+ * covers the whole frame (SCE/LFE for 1 channel, CPE for 2), compressed, chanBits 1..23 (16-bit; 20-bit; 24/32-bit
+ * with their usual shift bytes), mode 0 on both channels, predictor orders 0..16 or 31, header inside the packet.
+ * Regular packets are decoded by a pair of wavefronts per 64 packets (alac_duo.h); everything else is scanned
+ * first (decode_wave<SCAN>, alac_wave.h) and finished by the split pipeline (alac_split.h) or the whole-packet
+ * decoder. All of them produce identical bytes and status words; which one runs is a speed choice made per packet
+ * by the classifier, and waves are built from packets with the same (numU, numV).
  *
- * What "lean" buys: with the orders wave-uniform the predictor is compiled for exactly NA
- * taps and the warm-up test is scalar; the per-sample step has no data-dependent branch on its common path
- * (zero-run countdown, the in-range test and dead lanes are selects; only an escape code, the start of a
- * zero run or an error take the one slow branch); |diff| + rounding is one v_sad_u32 on a sign-biased history;
- * all products are 24-bit (v_mad_i32_i24 / v_mad_u32_u24), exact because chanBits <= 17 here.
+ * What "lean" buys: with the orders wave-uniform the predictor is compiled for exactly NA taps
+ * and the warm-up test is scalar; the per-sample steps are plain integer arithmetic on bit masks (no compare, no
+ * select: a v_cmp / v_cndmask pair costs a lone wave ~17 cycles, an add ~5); only an escape code, the start of a
+ * zero run or an error take the one slow branch; |diff| + rounding is one v_sad_u32 on a sign-biased history;
+ * products are 24-bit multiply-adds, exact because chanBits <= 23.
  */
 #ifndef ALAC_REGULAR_H
 #define ALAC_REGULAR_H
@@ -195,21 +197,9 @@ struct RingRd {
         const uint32_t r = (pos + bias) & 31u;
         return (uint32_t)(((((uint64_t)w0) << 32) | w1) << r >> 32);
     }
-    /* no branch: the cache moves by 0 or 1 dword (the slow path reseeks), w2 is re-read from LDS every step */
+    /* the cache moves by 0 or 1 dword per step (the slow path reseeks); the move is a bit mask, not a compare;
+     * w2 is re-read from LDS every step */
     ALAC_DEV void slide(W& wv, uint32_t pos) {
-        const uint32_t ni = (pos + bias) >> 5;
-        const bool cross = ni != widx;
-        w0 = cross ? w1 : w0;
-        w1 = cross ? w2 : w1;
-        widx = ni;
-        w2 = wv.ring_read((ni + 2u) & 31u);
-#ifdef ALAC_RING_DEBUG
-        if (ni + 2u < limit && w2 != __builtin_bswap32(base[ni + 2u]))
-            fprintf(stderr, "ring mismatch at dword %u (fill %u widx %u limit %u pend %d)\n", ni + 2u, fill, widx, limit, (int)pend);
-#endif
-    }
-    /* slide() without a compare: the move (0 or 1 dwords) becomes a bit mask */
-    ALAC_DEV void slide_mask(W& wv, uint32_t pos) {
         const uint32_t ni = (pos + bias) >> 5;
         const uint32_t cm = 0u - (ni - widx);
         w0 = (w1 & cm) | (w0 & ~cm);
@@ -359,61 +349,6 @@ ALAC_DEV int32_t gol_step(W& wv, const Bits& bits, RegLane<W>& s, uint32_t size,
             on_mask = (uint32_t)((int32_t)(i + 1u - ns_live) >> 31);
         }
     }
-    s.rd.slide_mask(wv, s.pos);
-    return del;
-}
-
-/*
- * One channel of a regular element, all lanes in lock step. NA = this channel's predictor order (wave-uniform).
- * LAST: this channel completes the frame (V of a pair, or the mono channel): unmix and emit PCM.
- */
-/* tentative result of the branch-free part of one Golomb sample (see regular_phase) */
-struct GolTent {
-    uint32_t pos2, mean2;
-    int32_t del;
-    bool dec, slow, on, inrun;
-};
-
-/* ---- one residual (DynDecomp, golomb.go:167-247) in two halves ------------------------------------------------
- * gol_tentative(): pure ALU, no branch, no state change. gol_commit(): the one rare branch (escape code, start of
- * a zero run, overrun), then the state update by selects and the reader slide. i = sample index, ns = the lane's
- * sample count (i >= ns: a dead step). */
-template <class W>
-ALAC_DEV void gol_tentative(const RegLane<W>& s, uint32_t kb, uint32_t i, uint32_t ns, GolTent& t) {
-    t.on = i < ns && s.err == 0;
-    t.inrun = s.zrem != 0;
-    t.dec = t.on && !t.inrun;
-    uint32_t m = s.mean >> 9;
-    const uint32_t k = umin(31u - clz32(m + 3u), kb);
-    m = (1u << k) - 1u;
-    const uint32_t w = s.rd.window(s.pos);
-    const uint32_t pre = clz32(~w);
-    const uint32_t v = (w << ((pre + 1u) & 31u)) >> (32u - k);
-    const bool big = v >= 2;
-    const uint32_t n = pre * m + (big ? v - 1u : 0u);
-    const uint32_t nd = n + s.zmode;
-    t.mean2 = s.pb * nd + s.mean - ((s.pb * s.mean) >> 9); /* golomb.go:215 */
-    if (n > 0xffffu) t.mean2 = 0xffffu;
-    t.slow = t.dec && (s.pos >= s.max_pos || pre >= 9 || ((t.mean2 << 2) < 512u && i + 1u < ns));
-    const int32_t half = (int32_t)((nd + 1u) >> 1); /* golomb.go:206-209 */
-    t.del = t.inrun ? 0 : ((nd & 1u) ? -half : half);
-    t.pos2 = s.pos + pre + k + (big ? 1u : 0u); /* prefix + 1, then k bits (v >= 2) or k - 1 */
-}
-template <class W>
-ALAC_DEV int32_t gol_commit(W& wv, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
-                            uint32_t chan_bits, uint32_t i, uint32_t ns, const GolTent& t) {
-    int32_t del = t.del;
-    if (wv.any(t.slow)) {
-        if (t.slow) {
-            del = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns);
-            s.rd.reseek(wv, s.pos);
-        }
-    }
-    const bool ok = t.dec && !t.slow;
-    s.pos = ok ? t.pos2 : s.pos;
-    s.mean = ok ? t.mean2 : s.mean;
-    s.zmode = ok ? 0u : s.zmode;
-    s.zrem = (t.on && t.inrun) ? s.zrem - 1u : s.zrem;
     s.rd.slide(wv, s.pos);
     return del;
 }
@@ -462,257 +397,49 @@ ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1
     return CB_POS ? (int32_t)((uint32_t)o << chan_shift) >> chan_shift : sext_cs(o, chan_shift);
 }
 
-/* what a phase does with the reconstructed samples */
+/* The same step for chanBits > 23 (32-bit streams without shift bytes): the literal form of predictor.go:99-684 on
+ * plain 32-bit arithmetic, where products and the countdown may wrap exactly as the reference's int32 do. */
+template <int NR, bool GEN, bool WRAP>
+ALAC_DEV int32_t predict_wide(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1], uint32_t na, int32_t del,
+                              uint32_t den_shift, int32_t den_half, uint32_t chan_shift) {
+    constexpr uint32_t BIAS = 0x80000000u;
+    int32_t top = (int32_t)(hb[NR] ^ BIAS);
+    if (GEN) {
+#pragma unroll
+        for (int j = 1; j < NR; ++j)
+            if (na == (uint32_t)j) ALAC_PICK(top, (int32_t)(hb[j] ^ BIAS));
+    }
+    int32_t d[NR];
+    int32_t acc = den_half;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        d[j] = top - (int32_t)(hb[j] ^ BIAS);
+        if (!GEN || (uint32_t)j < na) acc -= coef[j] * d[j];
+    }
+    const int32_t o = sext_cs(del + top + (acc >> den_shift), chan_shift);
+    if (del != 0) {
+        const int32_t sg = del > 0 ? 1 : -1;
+        int32_t del0 = del;
+        bool go = true;
+#pragma unroll
+        for (int j = NR - 1; j >= 0; --j) {
+            if (GEN && (uint32_t)j >= na) continue;
+            const int32_t sgn = sg > 0 ? sign_of(d[j]) : -sign_of(d[j]);
+            int32_t cj = coef[j] - sgn;
+            if (WRAP) cj = (int32_t)(int16_t)cj;
+            coef[j] = go ? cj : coef[j];
+            del0 -= go ? (int32_t)(na - (uint32_t)j) * ((sgn * d[j]) >> den_shift) : 0;
+            go = go && (sg > 0 ? del0 > 0 : del0 < 0);
+        }
+    }
+    return o;
+}
+
+/* what the predictor wave does with the reconstructed samples (alac_duo.h) */
 enum { OUT_UTILE = 0,  /* U of a pair: hand-off tile */
        OUT_STEREO = 1, /* V of a pair: unmix with U, PCM */
        OUT_MONO = 2,   /* single channel: PCM */
-       OUT_RAW = 3,    /* int32 samples into this lane's row (split pipeline, alac_split.h) */
-       OUT_NONE = 4 }; /* nothing: entropy scan only */
-
-template <class W, int NA, int OUT, bool NARROW>
-ALAC_DEV void regular_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
-                            uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
-                            uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb, uint32_t mode) {
-    constexpr bool LAST = OUT == OUT_STEREO || OUT == OUT_MONO;
-    constexpr bool CPE = OUT == OUT_STEREO;
-    constexpr bool RAW = OUT == OUT_RAW;
-    constexpr bool SCAN = OUT == OUT_NONE;
-    /* NARROW: chanBits <= 23, so every product fits the 24-bit multipliers and nothing in the adaptation can
-     * wrap; otherwise plain 32-bit arithmetic in the reference's literal form. mode != 0 (per lane): the delta
-     * pre-pass of decoder.go:307-309 runs on the residual stream first.
-     * shift_pos / sb: start of the shift-byte block and bits per value to merge (0 = none), LAST only.
-     * NA != 0: exactly NA taps, int32 coefficients (unpcBlock4/5/6/8). NA == 0: the general form for the
-     * wave-uniform order na_rt (0..16, 31) on NR = 16 register taps, coefficients wrapped to int16. */
-    constexpr bool GEN = NA == 0;
-    constexpr int NR = GEN ? 16 : NA;
-    /* orders other than 4/5/6/8 run unpcBlockGeneral: int16 coefficients (predictor.go:81-93) */
-    constexpr bool WRAP = !(NA == 4 || NA == 5 || NA == 6 || NA == 8);
-    const uint32_t na = GEN ? na_rt : (uint32_t)NA;
-    constexpr uint32_t BIAS = 0x80000000u;
-    const uint32_t kb = cfg.kb;
-    const uint32_t wb = (1u << kb) - 1u;
-    const uint32_t chan_shift = 32u - chan_bits;
-    const int32_t den_half = den_shift ? (int32_t)(1u << (den_shift - 1u)) : 0;
-    const uint32_t rnd_neg = (1u << den_shift) - 1u;
-
-    int32_t coef[NR];
-    uint32_t hb[NR + 1]; /* hb[j] = out[i-1-j] ^ BIAS: |a - b| of biased values is one unsigned sad */
-#pragma unroll
-    for (int j = 0; j < NR; ++j)
-        coef[j] = (!GEN || ((uint32_t)j < na && na != 31)) ? (int32_t)(int16_t)bits.get(hdr_pos + 16u + 16u * (uint32_t)j, 16) : 0;
-#pragma unroll
-    for (int j = 0; j <= NR; ++j) hb[j] = BIAS;
-    uint64_t pk_acc = 0; /* little-endian byte packer: whole dwords go to the stager */
-    uint32_t pk_n = 0;
-    const uint32_t bps = cfg.bps;
-    const uint64_t pk_msk = bps == 4 ? 0xffffffffull : ((1ull << (8u * bps)) - 1ull);
-    const bool merge_any = LAST && wv.any(sb != 0);
-    int32_t u_next = 0;
-    if (LAST && CPE) u_next = *wv.u_row(0);
-    int32_t dprev = 0;
-    const bool mode_any = !SCAN && wv.any(mode != 0);
-    /* decoder.go:307-309: UnpcBlock(numActive 31, denShift 0) over the residuals before the coefficient pass */
-    auto prepass = [&](uint32_t idx, int32_t del) -> int32_t {
-        if (!mode_any) return del;
-        const int32_t dd = idx == 0 ? del : sext_cs(del + dprev, chan_shift);
-        dprev = mode != 0 ? dd : dprev;
-        return mode != 0 ? dd : del;
-    };
-
-    /* one residual in two halves (gol_tentative / gol_commit above): the main loop puts the tentative half of
-     * sample i+1 in the same basic block as the predictor taps of sample i */
-    auto tentative = [&](uint32_t i, GolTent& t) { gol_tentative(s, kb, i, ns, t); };
-    auto commit = [&](uint32_t i, GolTent& t) -> int32_t { return gol_commit(wv, bits, s, size, kb, wb, chan_bits, i, ns, t); };
-    /* ---- predictor step for i > na (UnpcBlock, predictor.go:99-684) -------------------------------------------
-     * Taps walked from the highest down. The adaptation is sign-normalised: D0 = |del| shrinks by
-     * t_j = (na-j) * ((|d_j| + rnd) >> denShift) tap after tap and tap j adapts while the running total of the
-     * taps above it is still below D0. */
-    auto predict = [&](int32_t del) -> int32_t {
-        if (!NARROW) {
-            /* literal form of predictor.go:99-684 on 32-bit arithmetic */
-            int32_t top = (int32_t)(hb[NR] ^ BIAS);
-            if (GEN) {
-#pragma unroll
-                for (int j = 1; j < NR; ++j)
-                    if (na == (uint32_t)j) ALAC_PICK(top, (int32_t)(hb[j] ^ BIAS));
-            }
-            int32_t d[NR];
-            int32_t acc = den_half;
-#pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                d[j] = top - (int32_t)(hb[j] ^ BIAS);
-                if (!GEN || (uint32_t)j < na) acc -= coef[j] * d[j];
-            }
-            const int32_t o = sext_cs(del + top + (acc >> den_shift), chan_shift);
-            if (del != 0) {
-                const int32_t sg = del > 0 ? 1 : -1;
-                int32_t del0 = del;
-                bool go = true;
-#pragma unroll
-                for (int j = NR - 1; j >= 0; --j) {
-                    if (GEN && (uint32_t)j >= na) continue;
-                    const int32_t sgn = sg > 0 ? sign_of(d[j]) : -sign_of(d[j]);
-                    int32_t cj = coef[j] - sgn;
-                    if (WRAP) cj = (int32_t)(int16_t)cj;
-                    coef[j] = go ? cj : coef[j];
-                    del0 -= go ? (int32_t)(na - (uint32_t)j) * ((sgn * d[j]) >> den_shift) : 0;
-                    go = go && (sg > 0 ? del0 > 0 : del0 < 0);
-                }
-            }
-            return o;
-        }
-        return predict_narrow<NR, GEN, WRAP>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
-    };
-    /* ---- history, hand-off / unmix / PCM of sample i ------------------------------------------------------------ */
-    auto emit = [&](uint32_t i, int32_t o, bool on, int32_t u_pre, uint32_t sh_l, uint32_t sh_r) {
-#pragma unroll
-        for (int j = NR; j >= 1; --j) hb[j] = hb[j - 1];
-        hb[0] = (uint32_t)o ^ BIAS;
-        if (RAW) {
-            wv.st_push_if((uint32_t)o, on); /* one int32 sample per step into the lane's row */
-            return;
-        }
-        if (!LAST) {
-#ifndef ALAC_EXP_NO_U_STORE
-            *wv.u_row(i) = o; /* dead lanes write their own unused cell */
-#else
-            asm volatile("" ::"v"(o));
-#endif
-            return;
-        }
-        int32_t l = o, r = 0;
-        if (CPE) {
-            const int32_t u = u_pre, vv = o;
-            if (mix_res != 0) { /* matrix.go:40-41 */
-                l = u + vv - (ALAC_MUL24(mix_res, vv) >> mix_sh);
-                r = l - vv;
-            } else {
-                l = u;
-                r = vv;
-            }
-        }
-        if (cfg.bit_depth == 20) { /* matrix.go:77-78, 237 */
-            l = (int32_t)((uint32_t)l << 4);
-            r = (int32_t)((uint32_t)r << 4);
-        }
-        if (merge_any) { /* matrix.go:129-132, 266-268: (x << 8*bytesShifted) | shift value */
-            l = (int32_t)((uint32_t)l << sb) | (int32_t)sh_l;
-            r = (int32_t)((uint32_t)r << sb) | (int32_t)sh_r;
-        }
-        if (bps == 2 && CPE) {
-            wv.st_push_if(((uint32_t)l & 0xffffu) | ((uint32_t)r << 16), on);
-        } else {
-            /* generic widths: append bps bytes per sample, emit a dword whenever four are ready (all selects) */
-            pk_acc |= ((uint64_t)(uint32_t)l & pk_msk) << (8u * pk_n);
-            pk_n += on ? bps : 0u;
-            bool em = pk_n >= 4u;
-            wv.st_push_if((uint32_t)pk_acc, em);
-            pk_acc = em ? pk_acc >> 32 : pk_acc;
-            pk_n = em ? pk_n - 4u : pk_n;
-            if (CPE) {
-                pk_acc |= ((uint64_t)(uint32_t)r & pk_msk) << (8u * pk_n);
-                pk_n += on ? bps : 0u;
-                em = pk_n >= 4u;
-                wv.st_push_if((uint32_t)pk_acc, em);
-                pk_acc = em ? pk_acc >> 32 : pk_acc;
-                pk_n = em ? pk_n - 4u : pk_n;
-            }
-            /* a lane that is not `on` appended nothing: clear what the OR left above its valid bytes */
-            pk_acc &= pk_n ? ((1ull << (8u * pk_n)) - 1ull) : 0ull;
-        }
-    };
-    /* per-step memory prefetches of sample i: shift values (24/32-bit) and the U hand-off, one step ahead */
-    auto fetch = [&](uint32_t i, int32_t& u_pre, uint32_t& sh_l, uint32_t& sh_r) {
-        sh_l = sh_r = 0;
-        if (merge_any) {
-            /* both shift values of the frame sit side by side (decoder.go:492-502): one window */
-            const uint64_t sw = bits.window(shift_pos + i * (CPE ? 2u : 1u) * sb);
-            sh_l = sb ? (uint32_t)(sw >> (64u - sb)) : 0u;
-            sh_r = (CPE && sb) ? (uint32_t)((sw << sb) >> (64u - sb)) : 0u;
-        }
-        u_pre = 0;
-        if (LAST && CPE) {
-            /* row n_it <= frame_length exists: the tile ends in spare cells */
-            u_pre = u_next;
-#ifndef ALAC_EXP_NO_U_LOAD
-            u_next = *wv.u_row(i + 1u);
-#else
-            u_next = (int32_t)i;
-#endif
-        }
-    };
-
-    /* ---- head: out[0] = pc1[0], warm-up (predictor.go:53-79); also the whole block for copy / delta mode ------ */
-    const bool simple_all = SCAN || (GEN && (na == 0 || na == 31));
-    const uint32_t head = simple_all ? n_it : umin(na + 1u, n_it);
-    uint32_t i = 0;
-    for (; i < head; ++i) {
-        if ((i & 3u) == 0) s.rd.tick(wv); /* scalar test: bitstream ring refill, 4 steps ahead of need */
-        int32_t u_pre;
-        uint32_t sh_l, sh_r;
-        fetch(i, u_pre, sh_l, sh_r);
-        GolTent t;
-        tentative(i, t);
-        int32_t del = commit(i, t);
-        if (SCAN) continue; /* entropy scan: only the position matters */
-        del = prepass(i, del);
-        const int32_t o = (i == 0 || (GEN && na == 0)) ? del : sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
-        emit(i, o, t.on, u_pre, sh_l, sh_r);
-#ifndef ALAC_EXP_NO_FLUSH
-        if (LAST || RAW) wv.st_step(); /* collective */
-#endif
-    }
-    /* ---- main loop, software-pipelined by one sample: predictor of sample i with the Golomb code of i+1 -------- */
-    if (i < n_it) {
-        GolTent t;
-        tentative(i, t);
-        int32_t del = prepass(i, commit(i, t));
-        bool on = t.on;
-        for (; i < n_it; ++i) {
-            if ((i & 3u) == 0) s.rd.tick(wv);
-            int32_t u_pre;
-            uint32_t sh_l, sh_r;
-            fetch(i, u_pre, sh_l, sh_r);
-            GolTent tn;
-            tentative(i + 1u, tn);         /* chain 1: entropy code of the next sample (i + 1 >= ns: a dead step) */
-            const int32_t o = predict(del); /* chain 2: taps of this sample */
-            emit(i, o, on, u_pre, sh_l, sh_r);
-            del = prepass(i + 1u, commit(i + 1u, tn));
-            on = tn.on;
-#ifndef ALAC_EXP_NO_FLUSH
-            if (LAST || RAW) wv.st_step(); /* collective */
-#endif
-        }
-    }
-    if (LAST) wv.st_tail(pk_acc, s.err == 0 ? pk_n : 0u); /* bytes of the last, incomplete dword */
-}
-
-/* the order switch is scalar: NA is wave-uniform by construction of the waves */
-template <class W, int OUT, bool NARROW>
-ALAC_DEV void regular_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size,
-                               uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
-                               int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb, uint32_t mode) {
-    /* one instantiation per order 1..16 (exact tap count, no skips); 0 (copy) and 31 (delta) share the general one */
-    switch (na) {
-        case 1: regular_phase<W, 1, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 2: regular_phase<W, 2, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 3: regular_phase<W, 3, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 4: regular_phase<W, 4, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 5: regular_phase<W, 5, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 6: regular_phase<W, 6, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 7: regular_phase<W, 7, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 8: regular_phase<W, 8, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 9: regular_phase<W, 9, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 10: regular_phase<W, 10, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 11: regular_phase<W, 11, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 12: regular_phase<W, 12, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 13: regular_phase<W, 13, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 14: regular_phase<W, 14, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 15: regular_phase<W, 15, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        case 16: regular_phase<W, 16, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-        default: regular_phase<W, 0, OUT, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode); break;
-    }
-}
+       OUT_RAW = 3 };  /* int32 samples into this lane's row (split pipeline, alac_split.h) */
 
 /* Entropy scan of one channel for decode_wave<..., SCAN>: the lean Golomb loop with nothing behind it. */
 template <class W>
@@ -729,89 +456,24 @@ ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const Bits& bits, const uin
     s.pb = pb_local;
     const uint32_t my_ns = go ? ns : 0u;
     const uint32_t n_it = wv.max_u32(my_ns);
+    const uint32_t kb = cfg.kb, wb = (1u << kb) - 1u;
     s.rd.start(wv, s.pos);
-    regular_phase<W, 0, OUT_NONE, true>(wv, cfg, bits, s, size, my_ns, n_it, 0u, 0u, chan_bits, 0, 0u, 0u, 0u, 0u, 0u);
+    uint32_t ns_live = my_ns;
+    uint32_t on_mask = (uint32_t)((int32_t)(0u - ns_live) >> 31);
+    uint32_t i = 0;
+    for (; i + 4u <= n_it; i += 4u) { /* four steps per ring top-up, straight-line */
+        s.rd.tick(wv);
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) (void)gol_step(wv, bits, s, size, kb, wb, chan_bits, i + j, my_ns, ns_live, on_mask);
+    }
+    for (; i < n_it; ++i) {
+        if ((i & 3u) == 0) s.rd.tick(wv);
+        (void)gol_step(wv, bits, s, size, kb, wb, chan_bits, i, my_ns, ns_live, on_mask);
+    }
     if (go) {
         pos = s.pos;
         err = s.err;
     }
-}
-
-/*
- * decode_regular: every lane of the wave holds a regular packet with the same key = numU*32 + numV (lanes
- * without a packet pass live = false). Same contract as decode_wave.
- */
-template <class W>
-ALAC_DEV int32_t decode_regular(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
-                                uint8_t* out, uint32_t* frames_out) {
-    const Bits bits{pkt, size};
-    const bool cpe = cfg.num_channels == 2;
-    const uint32_t na_u = key >> 5, na_v = key & 31u;
-
-    RegLane<W> s;
-    s.rd.init(pkt, size);
-    s.err = 0;
-    s.max_pos = size * 8u;
-
-    /* header (accepted by classify_regular, so no error can arise here): decoder.go:213-235, 421-450 */
-    uint32_t pos = 23;
-    uint32_t ns = 0;
-    if (live) {
-        ns = cfg.frame_length;
-        if (bits.get(19, 4) >> 3) {
-            ns = bits.get(pos, 32);
-            pos += 32;
-        }
-    }
-    const int32_t mix_bits = (int32_t)bits.get(pos, 8);
-    const int32_t mix_res = (int32_t)(int8_t)bits.get(pos + 8, 8);
-    const uint32_t mix_sh = (uint32_t)mix_bits > 31u ? 31u : (uint32_t)mix_bits;
-    const uint32_t hdr_u = pos + 16u;
-    const uint32_t hdr_v = hdr_u + 16u + 16u * na_u;
-    const uint32_t hu = bits.get(hdr_u, 16);
-    const uint32_t hv = bits.get(hdr_v, 16);
-    const uint32_t bs = (bits.get(19, 4) >> 1) & 3u;
-    const uint32_t shift_pos = cpe ? hdr_v + 16u + 16u * na_v : hdr_v; /* decoder.go:289-293, 453-457 */
-    s.pos = shift_pos + bs * 8u * (cpe ? 2u : 1u) * ns;
-    const uint32_t chan_bits = cfg.bit_depth - 8u * bs + (cpe ? 1u : 0u);
-    /* the 16- and 20-bit writers ignore the shift buffer (matrix.go:30,66) */
-    const uint32_t sb = (cfg.bit_depth == 24 || cfg.bit_depth == 32) ? bs * 8u : 0u;
-    const uint32_t n_it = wv.max_u32(ns);
-    if (live) wv.st_begin(out);
-
-    /* ---- U (or the mono channel) ---- */
-    s.mean = cfg.mb;
-    s.zmode = 0;
-    s.zrem = 0;
-    s.pb = (cfg.pb * ((hu >> 5) & 7u)) / 4u; /* decoder.go:299 */
-    s.rd.start(wv, live ? s.pos : 0u);
-    if (cpe) regular_phase_na<W, OUT_UTILE, true>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u, 0u);
-    else regular_phase_na<W, OUT_MONO, true>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb, 0u);
-    uint32_t err_chan = 0;
-    /* ---- V ---- */
-    if (cpe) {
-        const bool u_failed = s.err != 0;
-        if (!u_failed && ((s.pos >> 3) > size + 4u || (s.pos >> 3) > size)) s.err = ST_MALFORMED; /* DynDecomp entry */
-        const int32_t err_u = s.err;
-        s.mean = cfg.mb;
-        s.zmode = 0;
-        s.zrem = 0;
-        s.pb = (cfg.pb * ((hv >> 5) & 7u)) / 4u;
-        s.rd.start(wv, (live && s.err == 0) ? s.pos : 0u);
-        regular_phase_na<W, OUT_STEREO, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb, 0u);
-        if (err_u == 0 && s.err != 0) err_chan = 1;
-    }
-    if (!live) return 0;
-    (void)wv.st_finish();
-    if (s.err) {
-        *frames_out = 0;
-        if (s.err == ST_MALFORMED) return ST_MALFORMED;
-        const uint32_t stage = cpe ? (uint32_t)(err_chan == 0 ? ALACGPU_STAGE_ENTROPY_U : ALACGPU_STAGE_ENTROPY_V)
-                                   : (uint32_t)ALACGPU_STAGE_ENTROPY;
-        return ALACGPU_STATUS(s.err, cpe ? ALACGPU_CTX_CPE : ALACGPU_CTX_SCE, stage);
-    }
-    *frames_out = ns;
-    return 0;
 }
 
 } /* namespace alac */

@@ -9,9 +9,8 @@
  *               Golomb loop only (no predictor, no PCM), records where every channel's entropy stream starts
  *               (ChanDesc) and settles the packet's status and frame count (PktDesc) — every error the
  *               reference can raise is raised here, in stream order;
- *   2. decode   decode_channel_task: one lane per (packet, channel), waves sorted by predictor order, the lean
- *               phase of alac_regular.h writing int32 samples to the task's row through the LDS stager
- *               (coalesced 128-B lines);
+ *   2. decode   decode_channel_task: one lane per (packet, channel), wave pairs (alac_duo.h) sorted by predictor
+ *               order, int32 samples to the task's row through the LDS stager (coalesced 128-B lines);
  *   3. interleave  interleave_frame: one thread per (packet, frame): unmix pairs (matrix.go:40-41), shift-byte
  *               merge (matrix.go:129-132), escape elements straight from the bitstream (decoder.go:326-345,
  *               507-535), PCM bytes in frame order (coalesced both ways), zero fill of unwritten slots.
@@ -21,7 +20,7 @@
 #ifndef ALAC_SPLIT_H
 #define ALAC_SPLIT_H
 
-#include "alac_regular.h"
+#include "alac_duo.h"
 
 namespace alac {
 
@@ -37,10 +36,12 @@ ALAC_DEV uint32_t chan_task_key(const DevCfg& cfg, const ChanDesc& d) {
 constexpr uint32_t NUM_TASK_KEYS = 64;
 constexpr uint32_t TASK_NONE = 0xffffu;
 
-/* samples of one channel: every lane of the wave holds a task with the same key (live = false: no task) */
-template <class W>
+/* samples of one channel, by the wave pair of alac_duo.h (ROLE: which of the two this caller is): every lane holds
+ * a task with the same key (live = false: no task) */
+template <class W, int ROLE>
 ALAC_DEV void decode_channel_task(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
                                   const ChanDesc& d, int32_t* row) {
+    constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
     const Bits bits{pkt, size};
     const uint32_t na = key & 31u;
     const bool narrow = (key & 32u) == 0;
@@ -59,15 +60,15 @@ ALAC_DEV void decode_channel_task(W& wv, const DevCfg& cfg, uint32_t key, bool l
     const uint32_t ns = live ? d.ns : 0u;
     const uint32_t chan_bits = live ? ((d.info >> CD_CHANBITS_SHIFT) & 63u) : 16u;
     const uint32_t n_it = wv.max_u32(ns);
-    if (live) wv.st_begin(reinterpret_cast<uint8_t*>(row));
-    s.rd.start(wv, s.pos);
+    if (DO_B && live) wv.st_begin(reinterpret_cast<uint8_t*>(row));
+    if (DO_A) s.rd.start(wv, s.pos);
     if (narrow)
-        regular_phase_na<W, OUT_RAW, true>(wv, na, cfg, bits, s, size, ns, n_it, d.hdr_pos, den_shift, chan_bits, 0, 0u, 0u,
-                                          0u, mode);
+        duo_phase_na<W, OUT_RAW, ROLE, false, true>(wv, na, cfg, bits, s, size, ns, n_it, d.hdr_pos, den_shift, chan_bits, 0, 0u,
+                                                    0u, 0u, mode);
     else
-        regular_phase_na<W, OUT_RAW, false>(wv, na, cfg, bits, s, size, ns, n_it, d.hdr_pos, den_shift, chan_bits, 0, 0u,
-                                           0u, 0u, mode);
-    if (live) (void)wv.st_finish();
+        duo_phase_na<W, OUT_RAW, ROLE, false, false>(wv, na, cfg, bits, s, size, ns, n_it, d.hdr_pos, den_shift, chan_bits, 0,
+                                                     0u, 0u, 0u, mode);
+    if (DO_B && live) (void)wv.st_finish();
 }
 
 /* PCM of frame i of one split packet. rows: the packet's sample rows, row r at rows + r*row_stride. */

@@ -82,8 +82,8 @@ __device__ unsigned long long g_duo_prof[16];
 #endif
 #include "alac_wave.h"
 #include "alac_regular.h"
-#include "alac_split.h"
 #include "alac_duo.h"
+#include "alac_split.h"
 
 namespace {
 
@@ -119,10 +119,9 @@ struct Plan {
 __shared__ uint32_t s_rows[kWave * kRowStride];                                  /* PCM stager rows */
 __shared__ unsigned long long s_optr[kWave];                                     /* PCM slot of each lane's packet */
 __shared__ __attribute__((aligned(16))) uint32_t s_ring[kWave * kRingStride];    /* bitstream rings */
-/* role queues of the wave pair (alac_duo.h): residuals A -> B and samples B -> A, double-buffered chunks */
+/* residual queue of the wave pair (alac_duo.h), A -> B, double-buffered chunks */
 constexpr uint32_t kQ = alac::DUO_CHUNK;
 __shared__ int32_t s_rq[2 * kQ * kWave];
-__shared__ int32_t s_sq[2 * kQ * kWave];
 
 /* U hand-off tile of one wave: frame_length rows of 64 cells and one spare row (the single-wave decoders read one
  * row ahead) */
@@ -205,11 +204,9 @@ struct GpuWave {
         *reinterpret_cast<uint4*>(&s_ring[lane * kRingStride + (slot >> 2) * 4u]) = make_uint4(a, b, c, d);
     }
     ALAC_DEV uint32_t ring_read(uint32_t slot) const { return s_ring[lane * kRingStride + slot]; }
-    /* role queues: row j of buffer buf holds step j of the chunk for all 64 lanes (conflict-free) */
+    /* residual queue: row j of buffer buf holds step j of the chunk for all 64 lanes (conflict-free) */
     ALAC_DEV void rq_write(uint32_t buf, uint32_t j, int32_t v) { s_rq[(buf * kQ + j) * kWave + lane] = v; }
     ALAC_DEV int32_t rq_read(uint32_t buf, uint32_t j) const { return s_rq[(buf * kQ + j) * kWave + lane]; }
-    ALAC_DEV void sq_write(uint32_t buf, uint32_t j, int32_t v) { s_sq[(buf * kQ + j) * kWave + lane] = v; }
-    ALAC_DEV int32_t sq_read(uint32_t buf, uint32_t j) const { return s_sq[(buf * kQ + j) * kWave + lane]; }
     /* chunk hand-over between the two waves of the workgroup: LDS traffic only, so outstanding global loads
      * (ring refills, U prefetch) and stores (U tile) are NOT waited for — __syncthreads() would drain them */
     ALAC_DEV void duo_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -427,8 +424,8 @@ alac_task_classify(alac::DevCfg cfg, const alac::ChanDesc* __restrict__ cd, cons
     if (threadIdx.x < alac::NUM_TASK_KEYS && hist[threadIdx.x]) atomicAdd(&plan->count[threadIdx.x], hist[threadIdx.x]);
 }
 
-/* one wavefront per 64 channel tasks with the same key: int32 samples of the channel into its row */
-__global__ void __launch_bounds__(kWave)
+/* a wave pair per 64 channel tasks with the same key: int32 samples of the channel into its row */
+__global__ void __launch_bounds__(2 * kWave, 2)
 alac_chan_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                  const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
                  const alac::ChanDesc* __restrict__ cd, int32_t* __restrict__ rows, uint64_t row_stride, uint32_t ppw) {
@@ -438,7 +435,8 @@ alac_chan_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint6
     for (uint32_t t = 1; t < plan->nk; ++t)
         if (plan->list_wave0[t] <= b) e = t;
     const uint32_t key = plan->list_key[e];
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & (kWave - 1u);
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t idx = (b - plan->list_wave0[e]) * ppw + lane;
     const bool live = lane < ppw && idx < plan->count[key];
     const uint32_t t = live ? perm[plan->pkt_start[key] + idx] : 0u;
@@ -457,7 +455,13 @@ alac_chan_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint6
     alac::ChanDesc d = cd[t];
     if (!live) d.hdr_pos = d.ent_pos = d.ns = 0;
     int32_t* row = rows + ((size_t)pkt * cfg.num_channels + slot) * row_stride;
-    alac::decode_channel_task<GpuWave>(wv, cfg, (uint32_t)__builtin_amdgcn_readfirstlane((int)key), live, p, size, d, row);
+    const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+    if (role != 0u) {
+        alac::decode_channel_task<GpuWave, alac::ROLE_B>(wv, cfg, ukey, live, p, size, d, row);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    alac::decode_channel_task<GpuWave, alac::ROLE_A>(wv, cfg, ukey, live, p, size, d, row);
 }
 
 /* one thread per (packet, frame) of the split packets: PCM in frame order. Blocks stride over the scanned
@@ -695,7 +699,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
             hipLaunchKernelGGL(alac_plan, dim3(1), dim3(256), 0, dec->stream, plan2, ppw2);
             hipLaunchKernelGGL(alac_scatter, dim3(nb2), dim3(256), 0, dec->stream, (const uint16_t*)dec->keys2.p,
                                (uint32_t)n_slots, plan2, (uint32_t*)dec->perm2.p);
-            hipLaunchKernelGGL(alac_chan_decode, dim3((uint32_t)max_waves(n_slots, ppw2)), dim3(kWave), 0, dec->stream, c,
+            hipLaunchKernelGGL(alac_chan_decode, dim3((uint32_t)max_waves(n_slots, ppw2)), dim3(2 * kWave), 0, dec->stream, c,
                                d_blob, d_offsets, d_sizes, (const uint32_t*)dec->perm2.p, (const Plan*)plan2,
                                (const alac::ChanDesc*)dec->cd.p, (int32_t*)dec->rows.p, rs, ppw2);
         }

@@ -14,8 +14,8 @@
 #define ALAC_DEV inline
 #include "../../saprobe-alac_amd/csrc/alac_wave.h"
 #include "../../saprobe-alac_amd/csrc/alac_regular.h"
-#include "../../saprobe-alac_amd/csrc/alac_split.h"
 #include "../../saprobe-alac_amd/csrc/alac_duo.h"
+#include "../../saprobe-alac_amd/csrc/alac_split.h"
 
 namespace {
 
@@ -51,12 +51,10 @@ struct HostWave {
         ring[slot + 3] = d;
     }
     uint32_t ring_read(uint32_t slot) const { return ring[slot]; }
-    /* role queues of alac_duo.h: one lane, both roles played by the same caller, so the barriers are no-ops */
-    int32_t rq[2][alac::DUO_CHUNK] = {{0}}, sq[2][alac::DUO_CHUNK] = {{0}};
+    /* residual queue of alac_duo.h: one lane, both roles played by the same caller, so the barriers are no-ops */
+    int32_t rq[2][alac::DUO_CHUNK] = {{0}};
     void rq_write(uint32_t buf, uint32_t j, int32_t v) { rq[buf][j] = v; }
     int32_t rq_read(uint32_t buf, uint32_t j) const { return rq[buf][j]; }
-    void sq_write(uint32_t buf, uint32_t j, int32_t v) { sq[buf][j] = v; }
-    int32_t sq_read(uint32_t buf, uint32_t j) const { return sq[buf][j]; }
     void duo_sync() {}
     void duo_sync_mem() {}
     int32_t* u_row(uint32_t i) { return &u_tile[i]; }
@@ -68,8 +66,7 @@ struct HostWave {
 /* variant: 0..3 = force that class's generic variant (any class must decode any packet correctly);
  *          -1   = route like alacgpu.hip does (wave-pair decoder of alac_duo.h for regular packets, split pipeline
  *                 for > 2 channels, whole-packet decoder otherwise);
- *          -2   = split pipeline for every non-regular packet, whatever the channel count;
- *          -3   = like -1 with the single-wave lean decoder (decode_regular) for regular packets.
+ *          -2   = split pipeline for every non-regular packet, whatever the channel count.
  * classes_out (may be null) gets the sort key / route. */
 extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* blob, const uint64_t* offsets,
                                      const uint32_t* sizes, size_t n, uint8_t* out, size_t out_stride,
@@ -100,11 +97,8 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
             const uint32_t key = alac::classify_regular(dc, p, sizes[i]);
             if (key != alac::KEY_IRREGULAR) {
                 if (classes_out) classes_out[i] = key;
-                if (variant == -3)
-                    status[i] = alac::decode_regular<HostWave>(wv, dc, key, true, p, sizes[i], o, &frames_out[i]);
-                else
-                    status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH>(wv, dc, key, true, p, sizes[i], o,
-                                                                                    &frames_out[i]);
+                status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH>(wv, dc, key, true, p, sizes[i], o,
+                                                                                &frames_out[i]);
                 continue;
             }
         }
@@ -121,7 +115,7 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
                 std::vector<int32_t> rows(rs * 8, 0x5a5a5a5a);
                 for (uint32_t sl = 0; sl < pd.nslots; ++sl) {
                     if (!(cd[sl].info & alac::CD_VALID) || (cd[sl].info & alac::CD_ESCAPE)) continue;
-                    alac::decode_channel_task<HostWave>(wv, dc, alac::chan_task_key(dc, cd[sl]), true, p, sizes[i], cd[sl],
+                    alac::decode_channel_task<HostWave, alac::ROLE_BOTH>(wv, dc, alac::chan_task_key(dc, cd[sl]), true, p, sizes[i], cd[sl],
                                                         rows.data() + rs * sl);
                 }
                 for (uint32_t f = 0; f < pd.frames; ++f)

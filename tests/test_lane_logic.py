@@ -15,7 +15,7 @@ def test_lane_matches_oracle_on_valid_streams(oracle, synth, lane_sim, helpers, 
         b = synth.gen_batch(cfg, 96, profile=prof, threads=4)
         ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=4)
         # every class variant must decode every packet (the order class is a speed choice only) ...
-        for variant in (-1, -2, -3, 0, 1, 2, 3):
+        for variant in (-1, -2, 0, 1, 2, 3):
             got = lane_sim(cfg, b.blob, b.offsets, b.sizes, variant=variant)
             helpers.assert_same_decode(cfg, ref, got, bpf, "profile %d variant %d" % (prof, variant))
         # ... and so must the unaligned-output path (direct stores instead of the LDS stager)
@@ -34,7 +34,7 @@ def test_lane_matches_oracle_on_corrupt_packets(oracle, synth, lane_sim, helpers
         b = synth.gen_batch(cfg, 48, profile=prof, threads=4)
         blob, offs, sizes = helpers.pack_packets(helpers.mutate_packets(b, rng, 400))
         ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=4)
-        for variant in (-1, -2, -3, 0, 3):
+        for variant in (-1, -2, 0, 3):
             got = lane_sim(cfg, blob, offs, sizes, variant=variant)
             helpers.assert_same_decode(cfg, ref, got, bpf, "fuzz profile %d variant %d" % (prof, variant))
         assert len(np.unique(ref[2])) > 3  # the corpus really reaches several error classes
