@@ -71,12 +71,12 @@ ALAC_DEV void decode_channel_task(W& wv, const DevCfg& cfg, uint32_t key, bool l
     if (DO_B && live) (void)wv.st_finish();
 }
 
-/* PCM of frame i of one split packet. rows: the packet's sample rows, row r at rows + r*row_stride. */
+/* PCM of frame i of one split packet, written at `frame` (num_channels * bps bytes; the kernel stages 256 frames
+ * in LDS and copies them out as whole lines). rows: the packet's sample rows, row r at rows + r*row_stride. */
 ALAC_DEV void interleave_frame(const DevCfg& cfg, const uint8_t* pkt, uint32_t size, const PktDesc& pd,
-                               const ChanDesc* cd, const int32_t* rows, size_t row_stride, uint32_t i, uint8_t* out) {
+                               const ChanDesc* cd, const int32_t* rows, size_t row_stride, uint32_t i, uint8_t* frame) {
     const Bits bits{pkt, size};
     const uint32_t num_chan = cfg.num_channels, bps = cfg.bps, depth = cfg.bit_depth;
-    uint8_t* frame = out + (size_t)i * num_chan * bps;
     for (uint32_t slot = 0; slot < pd.nslots; ++slot) {
         const ChanDesc d = cd[slot];
         if (!(d.info & CD_VALID) || (d.info & CD_SECOND) || i >= d.ns) continue;

@@ -465,24 +465,41 @@ alac_chan_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint6
 }
 
 /* one thread per (packet, frame) of the split packets: PCM in frame order. Blocks stride over the scanned
- * packets (the tail of the permutation that belongs to kKeyScan) x 256-frame slices. */
+ * packets (the tail of the permutation that belongs to kKeyScan) x 256-frame slices. A slice is assembled in LDS
+ * (a frame is 1..32 bytes at a byte offset of its own) and copied out as 16-byte pieces, whole lines at a time. */
 __global__ void __launch_bounds__(256)
 alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
                 const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
                 const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd, const int32_t* __restrict__ rows,
                 uint64_t row_stride, uint8_t* __restrict__ out, uint64_t out_stride, uint32_t blocks_per_pkt) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_slice[256 * 32];
     const uint32_t n_scan = plan->count[kKeyScan];
     const uint32_t first = plan->pkt_start[kKeyScan];
     const uint64_t items = (uint64_t)n_scan * blocks_per_pkt;
+    const uint32_t fb = cfg.num_channels * cfg.bps;
     for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
         const uint32_t pkt = perm[first + (uint32_t)(it / blocks_per_pkt)];
         const alac::PktDesc q = pd[pkt];
-        if (q.status != 0 || q.route != alac::ROUTE_SPLIT) continue;
-        const uint32_t f = (uint32_t)(it % blocks_per_pkt) * blockDim.x + threadIdx.x;
-        if (f >= q.frames) continue;
-        alac::interleave_frame(cfg, blob + offsets[pkt], sizes[pkt], q, cd + (size_t)pkt * 8u,
-                               rows + (size_t)pkt * cfg.num_channels * row_stride, (size_t)row_stride, f,
-                               out + (size_t)pkt * out_stride);
+        if (q.status != 0 || q.route != alac::ROUTE_SPLIT) continue; /* block-uniform */
+        const uint32_t f0 = (uint32_t)(it % blocks_per_pkt) * blockDim.x;
+        if (f0 >= q.frames) continue;
+        const uint32_t nf = min(q.frames - f0, (uint32_t)blockDim.x);
+        const uint32_t f = f0 + threadIdx.x;
+        if (threadIdx.x < nf)
+            alac::interleave_frame(cfg, blob + offsets[pkt], sizes[pkt], q, cd + (size_t)pkt * 8u,
+                                   rows + (size_t)pkt * cfg.num_channels * row_stride, (size_t)row_stride, f,
+                                   s_slice + threadIdx.x * fb);
+        __syncthreads();
+        uint8_t* dst = out + (size_t)pkt * out_stride + (size_t)f0 * fb; /* f0 * fb is a multiple of 256 */
+        const uint32_t total = nf * fb;
+        if (cfg.aligned16) {
+            for (uint32_t k = threadIdx.x * 16u; k + 16u <= total; k += 256u * 16u)
+                *reinterpret_cast<uint4*>(dst + k) = *reinterpret_cast<const uint4*>(s_slice + k);
+            for (uint32_t k = (total & ~15u) + threadIdx.x; k < total; k += 256u) dst[k] = s_slice[k];
+        } else {
+            for (uint32_t k = threadIdx.x; k < total; k += 256u) dst[k] = s_slice[k];
+        }
+        __syncthreads();
     }
 }
 

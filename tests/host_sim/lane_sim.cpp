@@ -119,7 +119,7 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
                                                         rows.data() + rs * sl);
                 }
                 for (uint32_t f = 0; f < pd.frames; ++f)
-                    alac::interleave_frame(dc, p, sizes[i], pd, cd, rows.data(), rs, f, o);
+                    alac::interleave_frame(dc, p, sizes[i], pd, cd, rows.data(), rs, f, o + (size_t)f * dc.num_channels * dc.bps);
                 continue;
             }
             /* ROUTE_LEGACY: fall through to the whole-packet decoder */
