@@ -38,7 +38,10 @@
 
 namespace alac {
 
-constexpr uint32_t DUO_CHUNK = 8; /* steps per queue buffer */
+#ifndef ALAC_DUO_CHUNK
+#define ALAC_DUO_CHUNK 16
+#endif
+constexpr uint32_t DUO_CHUNK = ALAC_DUO_CHUNK; /* steps per queue buffer (a multiple of 8) */
 enum { ROLE_A = 0, ROLE_B = 1, ROLE_BOTH = 2 };
 
 /*
@@ -191,7 +194,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
              * (HBM/L2) are all requested up front and their latency hides behind the taps of the first steps;
              * the history shift becomes register renaming across the unrolled steps */
             /* long predictors and the wide writers (64-bit shift windows): half chunks, or registers run out */
-            constexpr uint32_t UN = (NR <= ALAC_DUO_UN8_MAX && NARROW && (F16 || !LAST || RAW)) ? CH : CH / 2u;
+            constexpr uint32_t UN = (NR <= ALAC_DUO_UN8_MAX && NARROW && (F16 || !LAST || RAW)) ? 8u : 4u;
 #pragma nounroll
             for (uint32_t g = 0; g < CH; g += UN) {
                 int32_t dv[UN], uv[UN];
