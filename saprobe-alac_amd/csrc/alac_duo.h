@@ -295,7 +295,7 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bi
 }
 
 /*
- * decode_regular_duo: same contract as decode_regular (alac_regular.h) for the caller playing role A (or both):
+ * decode_regular_duo: same contract as decode_wave (alac_wave.h) for the caller playing role A (or both):
  * every lane holds a regular packet with the same key = numU*32 + numV, lanes without a packet pass live = false;
  * returns the status word and sets *frames_out. The caller playing role B passes the same arguments; its return
  * value and *frames_out mean nothing.
