@@ -244,33 +244,60 @@ alac_classify(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t
         if (hist[k]) atomicAdd(&plan->count[k], hist[k]);
 }
 
-/* One block: exclusive scan of the key histogram in dispatch order (highest key first: irregular packets, then
- * the longest predictors; the kernel ends when its last wave does, so the slowest waves get the lowest block ids). */
-__global__ void __launch_bounds__(256) alac_plan(Plan* plan, uint32_t ppw) {
+/* One wavefront: exclusive scan of the key histogram in dispatch order (highest key first: irregular packets, then
+ * the longest predictors; a kernel ends when its last wave does, so the slowest waves get the lowest block ids).
+ * Each lane owns a run of consecutive dispatch positions; the lane totals are scanned with shuffles. */
+__global__ void __launch_bounds__(kWave) alac_plan(Plan* plan, uint32_t ppw) {
     __shared__ uint32_t cnt[kKeys];
-    for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x) cnt[k] = plan->count[k];
+    for (uint32_t k = threadIdx.x; k < kKeys; k += kWave) cnt[k] = plan->count[k];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t p = 0, w = 0, nk = 0;
-        for (int k = (int)kKeys - 1; k >= 0; --k) {
-            if (k == 1023) plan->irr_waves = w;
-            const uint32_t c = cnt[k];
-            cnt[k] = p; /* becomes pkt_start */
-            if (c) {
-                plan->list_key[nk] = (uint32_t)k;
-                plan->list_wave0[nk] = w;
-                ++nk;
-                p += c;
-                w += (c + ppw - 1) / ppw;
-            }
-        }
-        plan->nk = nk;
-        plan->total_waves = w;
+    constexpr uint32_t R = (kKeys + kWave - 1) / kWave;
+    const uint32_t q0 = threadIdx.x * R; /* dispatch position q holds key kKeys - 1 - q */
+    uint32_t p = 0, w = 0, z = 0, wi = 0;
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t q = q0 + r;
+        if (q >= kKeys) break;
+        const uint32_t key = kKeys - 1u - q;
+        const uint32_t c = cnt[key];
+        const uint32_t cw = (c + ppw - 1) / ppw;
+        p += c;
+        w += cw;
+        z += c ? 1u : 0u;
+        wi += key >= 1024u ? cw : 0u;
     }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x) {
-        plan->pkt_start[k] = cnt[k];
-        plan->cursor[k] = 0;
+    /* inclusive scan over the 64 lanes, then make it exclusive */
+    uint32_t ip = p, iw = w, iz = z, ii = wi;
+#pragma unroll
+    for (int o = 1; o < (int)kWave; o <<= 1) {
+        const uint32_t tp = (uint32_t)__shfl_up((int)ip, o, kWave), tw = (uint32_t)__shfl_up((int)iw, o, kWave);
+        const uint32_t tz = (uint32_t)__shfl_up((int)iz, o, kWave), ti = (uint32_t)__shfl_up((int)ii, o, kWave);
+        if ((int)threadIdx.x >= o) {
+            ip += tp;
+            iw += tw;
+            iz += tz;
+            ii += ti;
+        }
+    }
+    uint32_t ep = ip - p, ew = iw - w, ez = iz - z;
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t q = q0 + r;
+        if (q >= kKeys) break;
+        const uint32_t key = kKeys - 1u - q;
+        const uint32_t c = cnt[key];
+        plan->pkt_start[key] = ep;
+        plan->cursor[key] = 0;
+        if (c) {
+            plan->list_key[ez] = key;
+            plan->list_wave0[ez] = ew;
+            ++ez;
+            ep += c;
+            ew += (c + ppw - 1) / ppw;
+        }
+    }
+    if (threadIdx.x == kWave - 1u) {
+        plan->nk = iz;
+        plan->total_waves = iw;
+        plan->irr_waves = ii;
     }
 }
 
@@ -684,7 +711,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
     HIP_TRY(hipMemsetAsync(plan, 0, sizeof(Plan), dec->stream));
     hipLaunchKernelGGL(alac_classify, dim3(nb), dim3(256), 0, dec->stream, c, d_blob, d_offsets, d_sizes, (uint32_t)n,
                        (uint16_t*)dec->cls.p, plan);
-    hipLaunchKernelGGL(alac_plan, dim3(1), dim3(256), 0, dec->stream, plan, ppw);
+    hipLaunchKernelGGL(alac_plan, dim3(1), dim3(kWave), 0, dec->stream, plan, ppw);
     hipLaunchKernelGGL(alac_scatter, dim3(nb), dim3(256), 0, dec->stream, (const uint16_t*)dec->cls.p, (uint32_t)n, plan,
                        (uint32_t*)dec->perm.p);
     const uint32_t slot = (uint32_t)(dec->launches % kTimingSlots);
@@ -713,7 +740,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
             hipLaunchKernelGGL(alac_task_classify, dim3(nb2), dim3(256), 0, dec->stream, c, (const alac::ChanDesc*)dec->cd.p,
                                (const alac::PktDesc*)dec->pd.p, (const uint16_t*)dec->cls.p, (uint32_t)n_slots,
                                (uint16_t*)dec->keys2.p, plan2);
-            hipLaunchKernelGGL(alac_plan, dim3(1), dim3(256), 0, dec->stream, plan2, ppw2);
+            hipLaunchKernelGGL(alac_plan, dim3(1), dim3(kWave), 0, dec->stream, plan2, ppw2);
             hipLaunchKernelGGL(alac_scatter, dim3(nb2), dim3(256), 0, dec->stream, (const uint16_t*)dec->keys2.p,
                                (uint32_t)n_slots, plan2, (uint32_t*)dec->perm2.p);
             hipLaunchKernelGGL(alac_chan_decode, dim3((uint32_t)max_waves(n_slots, ppw2)), dim3(2 * kWave), 0, dec->stream, c,
