@@ -26,6 +26,8 @@
 #ifndef ALAC_DUO_H
 #define ALAC_DUO_H
 
+#include <type_traits>
+
 #include "alac_regular.h"
 
 #ifndef ALAC_DUO_UN8_MAX
@@ -96,10 +98,14 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
         dprev = mode != 0 ? dd : dprev;
         return mode != 0 ? dd : del;
     };
-    auto predict = [&](int32_t del) -> int32_t {
-        if (NARROW) return predict_narrow<NR, GEN, WRAP, !RAW>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
-        return predict_wide<NR, GEN, WRAP>(coef, hb, na, del, den_shift, den_half, chan_shift);
+    /* wrap: the int16 coefficient wrap of unpcBlockGeneral (predictor.go:664,675) is applied in this step */
+    auto predict = [&](int32_t del, auto wrap) -> int32_t {
+        constexpr bool WR = decltype(wrap)::value;
+        if (NARROW) return predict_narrow<NR, GEN, WR, !RAW>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
+        return predict_wide<NR, GEN, WR>(coef, hb, na, del, den_shift, den_half, chan_shift);
     };
+    using wrap_yes = std::integral_constant<bool, WRAP>;
+    using wrap_no = std::integral_constant<bool, false>;
     const uint32_t nzm = mix_res != 0 ? 0xffffffffu : 0u; /* per lane: the pair is matrixed (matrix.go:34) */
 
     /* A: residuals of chunk c (DynDecomp, golomb.go:167-247). Whole chunks run as two straight-line groups of four
@@ -195,25 +201,41 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
              * the history shift becomes register renaming across the unrolled steps */
             /* long predictors and the wide writers (64-bit shift windows): half chunks, or registers run out */
             constexpr uint32_t UN = (NR <= ALAC_DUO_UN8_MAX && NARROW && (F16 || !LAST || RAW)) ? 8u : 4u;
+            auto groups = [&](auto wrap) {
 #pragma nounroll
-            for (uint32_t g = 0; g < CH; g += UN) {
-                int32_t dv[UN], uv[UN];
-                uint64_t sv[UN];
+                for (uint32_t g = 0; g < CH; g += UN) {
+                    int32_t dv[UN], uv[UN];
+                    uint64_t sv[UN];
 #pragma unroll
-                for (uint32_t j = 0; j < UN; ++j) {
-                    dv[j] = wv.rq_read(buf, g + j);
-                    uv[j] = 0;
-                    sv[j] = 0;
-                    if (CPE) uv[j] = *wv.u_row(c * CH + g + j);
-                    if (merge_any) sv[j] = bits.window(shift_pos + (c * CH + g + j) * sstep);
+                    for (uint32_t j = 0; j < UN; ++j) {
+                        dv[j] = wv.rq_read(buf, g + j);
+                        uv[j] = 0;
+                        sv[j] = 0;
+                        if (CPE) uv[j] = *wv.u_row(c * CH + g + j);
+                        if (merge_any) sv[j] = bits.window(shift_pos + (c * CH + g + j) * sstep);
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < UN; ++j)
+                        put(c * CH + g + j, predict(dv[j], wrap), uv[j], sv[j]);
+                    /* collective of wave B, once per group: a lane row holds 64 dwords, a flush takes 32, and a
+                     * group adds at most 8 steps x 2 dwords */
+                    if (LAST) wv.st_step();
                 }
+            };
+            if (WRAP) {
+                /* A coefficient moves by at most 1 per step, so one that is further than a chunk away from the
+                 * int16 limits cannot wrap inside this chunk: test once per chunk and run the chunk without the
+                 * per-tap, per-step sign extension (one instruction of ten) unless some lane is that close. */
+                constexpr uint32_t T = 32767u - CH;
+                uint32_t far = 0;
 #pragma unroll
-                for (uint32_t j = 0; j < UN; ++j)
-                    put(c * CH + g + j, predict(dv[j]), uv[j], sv[j]);
-                /* collective of wave B, once per group: a lane row holds 64 dwords, a flush takes 32, and a group
-                 * adds at most 8 steps x 2 dwords */
-                if (LAST) wv.st_step();
+                for (int j = 0; j < NR; ++j) far = umax(far, (uint32_t)coef[j] + T);
+                if (!wv.any(far > 2u * T)) {
+                    groups(wrap_no{});
+                    return;
+                }
             }
+            groups(wrap_yes{});
             return;
         }
 #pragma nounroll
@@ -224,7 +246,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             int32_t o;
             if (i == 0 || (GEN && na == 0)) o = del;
             else if (i <= na || (GEN && na == 31)) o = sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
-            else o = predict(del);
+            else o = predict(del, wrap_yes{});
             put(i, o, CPE ? *wv.u_row(i) : 0, merge_any ? bits.window(shift_pos + i * sstep) : 0ull);
             if (LAST) wv.st_step();
         }

@@ -404,6 +404,11 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     /* the key is wave-uniform (one key per workgroup): scalar branches pick the variant */
     const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
     if (role != 0u) {
+        /* the kernel ends with its slowest workgroup, and that is one with long predictors (role B grows by nine
+         * instructions per tap): those predictor waves go ahead of the shorter ones they share a SIMD with */
+        const uint32_t na_max = max(ukey >> 5, ukey & 31u);
+        if (na_max > 8u && na_max != 31u) __builtin_amdgcn_s_setprio(2);
+        else if (na_max == 8u) __builtin_amdgcn_s_setprio(1);
         (void)alac::decode_regular_duo<GpuWave, alac::ROLE_B>(wv, cfg, ukey, live, p, size, o, &frames);
 #ifdef ALAC_DUO_PROF
         if (lane == 0)
