@@ -153,3 +153,24 @@ def test_24bit_shift_and_8ch_full_frames(pkg, synth, oracle, helpers, gpu_decode
             got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
         assert (got[2] == 0).all() and np.array_equal(got[1], b.frames)
         assert np.array_equal(got[0], b.pcm)
+
+
+@pytest.mark.parametrize("depth,ch,fl", [(16, 2, 33), (16, 2, 47), (16, 2, 1000), (16, 1, 4095), (24, 2, 129),
+                                         (20, 1, 65), (32, 2, 200), (16, 2, 4097)])
+def test_wave_pair_chunk_tails_and_full_waves(pkg, oracle, synth, helpers, gpu_decoder_factory, monkeypatch, depth, ch, fl):
+    """The wave pair of alac_duo.h works in chunks of 16 steps and groups of 4 / 8: frame lengths around those
+    multiples, partial frames inside a wave, and full 64-lane waves (forced: a small batch is normally spread over
+    narrow waves) with several sort keys per batch."""
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    for ppw in ("64", "16", None):
+        if ppw is None:
+            monkeypatch.delenv("ALACGPU_PPW", raising=False)
+        else:
+            monkeypatch.setenv("ALACGPU_PPW", ppw)
+        with gpu_decoder_factory(cfg) as dec:
+            for prof, n in ((synth.PROFILE_MUSIC, 333), (synth.PROFILE_STRESS, 260)):
+                b = synth.gen_batch(cfg, n, profile=prof, base_seed=fl * 131 + depth, threads=8)
+                ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=8)
+                got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
+                helpers.assert_same_decode(cfg, ref, got, bpf, "ppw %s profile %d" % (ppw, prof))

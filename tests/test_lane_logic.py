@@ -38,3 +38,16 @@ def test_lane_matches_oracle_on_corrupt_packets(oracle, synth, lane_sim, helpers
             got = lane_sim(cfg, blob, offs, sizes, variant=variant)
             helpers.assert_same_decode(cfg, ref, got, bpf, "fuzz profile %d variant %d" % (prof, variant))
         assert len(np.unique(ref[2])) > 3  # the corpus really reaches several error classes
+
+
+@pytest.mark.parametrize("depth,ch,fl", [(16, 2, 33), (16, 2, 47), (16, 2, 1000), (16, 1, 4095), (24, 2, 129),
+                                         (20, 1, 65), (32, 2, 200), (16, 2, 4097)])
+def test_wave_pair_chunk_tails(oracle, synth, lane_sim, helpers, depth, ch, fl):
+    """alac_duo.h works in chunks of 16 steps and groups of 4 / 8: frame lengths around those multiples."""
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    for prof in (synth.PROFILE_MUSIC, synth.PROFILE_STRESS):
+        b = synth.gen_batch(cfg, 48, profile=prof, base_seed=fl * 131 + depth, threads=4)
+        ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=4)
+        got = lane_sim(cfg, b.blob, b.offsets, b.sizes, variant=-1)
+        helpers.assert_same_decode(cfg, ref, got, bpf, "profile %d" % prof)
