@@ -54,7 +54,7 @@ enum { ROLE_A = 0, ROLE_B = 1, ROLE_BOTH = 2 };
  * mode (per lane) != 0: the delta pre-pass of decoder.go:307-309 runs on the residual stream first (split
  * pipeline only: regular packets have mode 0).
  */
-template <class W, int NA, int OUT, int ROLE, bool F16, bool NARROW>
+template <class W, int NA, int OUT, int ROLE, bool F16, bool NARROW, bool EA>
 ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
                         uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
                         uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb, uint32_t mode) {
@@ -66,7 +66,11 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
     constexpr int NR = GEN ? 16 : NA;
     constexpr bool WRAP = !(NA == 4 || NA == 5 || NA == 6 || NA == 8); /* predictor.go:81-93 */
     constexpr uint32_t BIAS = 0x80000000u;
-    constexpr uint32_t CH = DUO_CHUNK;
+    /* EA: the PCM writer runs in wave A (long predictors: B is the longer of the two). Samples then go B -> A
+     * through the second half of each queue buffer, in chunks of half the size, and A writes them two chunks late. */
+    constexpr bool EMIT_A = EA && LAST && !RAW;
+    constexpr bool DO_EMIT = EMIT_A ? DO_A : DO_B;
+    constexpr uint32_t CH = EMIT_A ? DUO_CHUNK / 2u : DUO_CHUNK;
     const uint32_t na = GEN ? na_rt : (uint32_t)NA;
     const uint32_t kb = cfg.kb;
     const uint32_t wb = (1u << kb) - 1u;
@@ -88,7 +92,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
     uint32_t pk_n = 0;
     const uint32_t bps = cfg.bps;
     const uint64_t pk_msk = bps == 4 ? 0xffffffffull : ((1ull << (8u * bps)) - 1ull);
-    const bool merge_any = DO_B && LAST && !F16 && !RAW && wv.any(sb != 0);
+    const bool merge_any = DO_EMIT && LAST && !F16 && !RAW && wv.any(sb != 0);
     /* decoder.go:307-309: UnpcBlock(numActive 31, denShift 0) over the residuals before the coefficient pass */
     const bool mode_any = DO_B && wv.any(mode != 0);
     int32_t dprev = 0;
@@ -132,16 +136,9 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             wv.rq_write(buf, j, gol_step(wv, bits, s, size, kb, wb, chan_bits, i, ns, ns_live, on_mask));
         }
     };
-    /* B: sample i is reconstructed: history; then the U hand-off tile, or unmix / shift merge / PCM.
+    /* PCM of frame i from its last channel's sample o (unmix / shift merge / packing / stager).
      * u: the U sample of frame i (pairs), sw: window on the frame's shift values (24/32-bit) */
-    auto put = [&](uint32_t i, int32_t o, int32_t u, uint64_t sw) {
-#pragma unroll
-        for (int t = NR; t >= 1; --t) hb[t] = hb[t - 1];
-        hb[0] = (uint32_t)o ^ BIAS;
-        if (!LAST) {
-            *wv.u_row(i) = o; /* dead lanes write their own unused cell */
-            return;
-        }
+    auto emit = [&](uint32_t i, int32_t o, int32_t u, uint64_t sw) {
         const bool on = i < ns;
         if (RAW) {
             wv.st_push_if((uint32_t)o, on); /* one int32 sample per step into the lane's row */
@@ -188,6 +185,43 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             pk_acc &= pk_n ? ((1ull << (8u * pk_n)) - 1ull) : 0ull;
         }
     };
+    /* B: sample i (step j of chunk buffer buf) is reconstructed: history; then the U hand-off tile, the sample
+     * queue to wave A, or the writer */
+    auto put = [&](uint32_t buf, uint32_t j, uint32_t i, int32_t o, int32_t u, uint64_t sw) {
+#pragma unroll
+        for (int t = NR; t >= 1; --t) hb[t] = hb[t - 1];
+        hb[0] = (uint32_t)o ^ BIAS;
+        if (!LAST) *wv.u_row(i) = o; /* dead lanes write their own unused cell */
+        else if (EMIT_A) wv.rq_write(buf, CH + j, o);
+        else emit(i, o, u, sw);
+    };
+    /* A (EMIT_A): inputs of the chunk it writes, requested before the Golomb work of the iteration */
+    int32_t sq_v[CH], u_v[CH];
+    uint64_t sw_v[CH];
+    const uint32_t sstep_a = (CPE ? 2u : 1u) * sb;
+    auto fetch_chunk = [&](uint32_t c) {
+        const uint32_t buf = c & 1u;
+#pragma unroll
+        for (uint32_t j = 0; j < CH; ++j) {
+            const uint32_t i = c * CH + j;
+            sq_v[j] = 0;
+            u_v[j] = 0;
+            sw_v[j] = 0;
+            if (i < n_it) { /* scalar: rows past n_it do not exist in the tile */
+                sq_v[j] = wv.rq_read(buf, CH + j);
+                if (CPE) u_v[j] = *wv.u_row(i);
+                if (merge_any) sw_v[j] = bits.window(shift_pos + i * sstep_a);
+            }
+        }
+    };
+    auto emit_chunk = [&](uint32_t c) {
+#pragma unroll
+        for (uint32_t j = 0; j < CH; ++j) {
+            const uint32_t i = c * CH + j;
+            if (i < n_it) emit(i, sq_v[j], u_v[j], sw_v[j]);
+        }
+        wv.st_step(); /* collective of wave A */
+    };
     /* B: samples of chunk c (UnpcBlock, predictor.go:45-684): out[0] = residual, warm-up up to na (:53-79),
      * copy (0) / delta (31) modes, then the adaptive taps */
     auto predict_chunk = [&](uint32_t c) {
@@ -200,7 +234,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
              * (HBM/L2) are all requested up front and their latency hides behind the taps of the first steps;
              * the history shift becomes register renaming across the unrolled steps */
             /* long predictors and the wide writers (64-bit shift windows): half chunks, or registers run out */
-            constexpr uint32_t UN = (NR <= ALAC_DUO_UN8_MAX && NARROW && (F16 || !LAST || RAW)) ? 8u : 4u;
+            constexpr uint32_t UN = (NR <= ALAC_DUO_UN8_MAX && NARROW && (F16 || !LAST || RAW || EMIT_A)) ? 8u : 4u;
             auto groups = [&](auto wrap) {
 #pragma nounroll
                 for (uint32_t g = 0; g < CH; g += UN) {
@@ -211,15 +245,15 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
                         dv[j] = wv.rq_read(buf, g + j);
                         uv[j] = 0;
                         sv[j] = 0;
-                        if (CPE) uv[j] = *wv.u_row(c * CH + g + j);
-                        if (merge_any) sv[j] = bits.window(shift_pos + (c * CH + g + j) * sstep);
+                        if (CPE && !EMIT_A) uv[j] = *wv.u_row(c * CH + g + j);
+                        if (!EMIT_A && merge_any) sv[j] = bits.window(shift_pos + (c * CH + g + j) * sstep);
                     }
 #pragma unroll
                     for (uint32_t j = 0; j < UN; ++j)
-                        put(c * CH + g + j, predict(dv[j], wrap), uv[j], sv[j]);
-                    /* collective of wave B, once per group: a lane row holds 64 dwords, a flush takes 32, and a
-                     * group adds at most 8 steps x 2 dwords */
-                    if (LAST) wv.st_step();
+                        put(buf, g + j, c * CH + g + j, predict(dv[j], wrap), uv[j], sv[j]);
+                    /* collective of the writing wave, once per group: a lane row holds 64 dwords, a flush takes
+                     * 32, and a group adds at most 8 steps x 2 dwords */
+                    if (LAST && !EMIT_A) wv.st_step();
                 }
             };
             if (WRAP) {
@@ -247,34 +281,43 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             if (i == 0 || (GEN && na == 0)) o = del;
             else if (i <= na || (GEN && na == 31)) o = sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
             else o = predict(del, wrap_yes{});
-            put(i, o, CPE ? *wv.u_row(i) : 0, merge_any ? bits.window(shift_pos + i * sstep) : 0ull);
-            if (LAST) wv.st_step();
+            put(buf, j, i, o, (CPE && !EMIT_A) ? *wv.u_row(i) : 0,
+                (!EMIT_A && merge_any) ? bits.window(shift_pos + i * sstep) : 0ull);
+            if (LAST && !EMIT_A) wv.st_step();
         }
     };
 
-    /* iteration c: A produces chunk c while B consumes chunk c-1; the barrier publishes R[c & 1] */
+    /* iteration c: A produces residual chunk c while B consumes chunk c-1 (and, EMIT_A, A writes the PCM of chunk
+     * c-2 from the samples B queued in iteration c-1); the barrier publishes the buffers written in the iteration */
     const uint32_t nch = (n_it + CH - 1u) / CH;
-    for (uint32_t c = 0; c <= nch; ++c) {
+    const uint32_t iters = nch + (EMIT_A ? 2u : 1u);
+    for (uint32_t c = 0; c < iters; ++c) {
         ALAC_DUO_STAMP(0);
-#ifndef ALAC_EXP_DUO_NO_GOLOMB
         if (DO_A) {
+            if (EMIT_A && c >= 2u) fetch_chunk(c - 2u);
             if (c < nch) golomb_chunk(c);
         }
-#endif
         ALAC_DUO_STAMP(1);
-#ifndef ALAC_EXP_DUO_NO_B
         if (DO_B) {
-            if (c >= 1u) predict_chunk(c - 1u);
+            if (c >= 1u && c <= nch) predict_chunk(c - 1u);
         }
-#endif
         ALAC_DUO_STAMP(2);
+        if (DO_A && EMIT_A) {
+            if (c >= 2u) emit_chunk(c - 2u);
+        }
         ALAC_DUO_STAMP(3);
         wv.duo_sync();
         ALAC_DUO_STAMP(4);
     }
-    if (DO_B && LAST) wv.st_tail(pk_acc, pk_n); /* bytes of the last, incomplete dword */
-    if (!LAST) wv.duo_sync_mem();               /* B's tile stores land before it reads them back as V's partner */
+    if (DO_EMIT && LAST) wv.st_tail(pk_acc, pk_n); /* bytes of the last, incomplete dword */
+    if (!LAST) wv.duo_sync_mem();                  /* the U tile is complete before anyone loads from it */
 }
+
+/* which wave writes the PCM of a channel with predictor order na: B's step grows by nine instructions per tap, A's
+ * does not; for single channels the writer balances the pair better in A from order 5 on (mono 16-bit: 1.93 ->
+ * 1.63 ms). Not for pairs: the writer then needs the U tile and the shift bytes from HBM, and in wave A every wait
+ * for the bitstream ring (vmcnt counts in order) would also wait for those loads (measured: 3.15 -> 3.55 ms). */
+ALAC_DEV constexpr bool duo_emit_in_a(uint32_t na, bool cpe) { return !cpe && na >= 5u && na <= 16u; }
 
 /* the order switch is scalar: NA is wave-uniform by construction of the waves. Role A never looks at the order. */
 template <class W, int OUT, int ROLE, bool F16, bool NARROW = true>
@@ -283,12 +326,18 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bi
                            int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb, uint32_t mode = 0u) {
 #define ALAC_DUO_CASE(N)                                                                                              \
     case N:                                                                                                           \
-        duo_phase<W, N, OUT, ROLE, F16, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,      \
-                                                mix_res, mix_sh, na, shift_pos, sb, mode);                            \
+        duo_phase<W, N, OUT, ROLE, F16, NARROW, CAN_EA && duo_emit_in_a(N, OUT == OUT_STEREO)>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, \
+                                                                       den_shift, chan_bits, mix_res, mix_sh, na,     \
+                                                                       shift_pos, sb, mode);                          \
         break;
+    constexpr bool CAN_EA = OUT == OUT_STEREO || OUT == OUT_MONO; /* phases that write PCM */
     if (ROLE == ROLE_A) {
-        duo_phase<W, 0, OUT, ROLE, F16, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits, mix_res,
-                                                mix_sh, na, shift_pos, sb, mode);
+        if (CAN_EA && duo_emit_in_a(na, OUT == OUT_STEREO))
+            duo_phase<W, 0, OUT, ROLE, F16, NARROW, true>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
+                                                          mix_res, mix_sh, na, shift_pos, sb, mode);
+        else
+            duo_phase<W, 0, OUT, ROLE, F16, NARROW, false>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
+                                                           mix_res, mix_sh, na, shift_pos, sb, mode);
         return;
     }
     switch (na) {
@@ -309,8 +358,8 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bi
         ALAC_DUO_CASE(15)
         ALAC_DUO_CASE(16)
         default:
-            duo_phase<W, 0, OUT, ROLE, F16, NARROW>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
-                                                    mix_res, mix_sh, na, shift_pos, sb, mode);
+            duo_phase<W, 0, OUT, ROLE, F16, NARROW, false>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
+                                                           mix_res, mix_sh, na, shift_pos, sb, mode);
             break;
     }
 #undef ALAC_DUO_CASE
@@ -359,7 +408,10 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     /* the 16- and 20-bit writers ignore the shift buffer (matrix.go:30,66) */
     const uint32_t sb = (cfg.bit_depth == 24 || cfg.bit_depth == 32) ? bs * 8u : 0u;
     const uint32_t n_it = wv.max_u32(ns);
-    if (DO_B && live) wv.st_begin(out);
+    /* the stager belongs to the wave that writes the PCM of the last channel (duo_emit_in_a) */
+    const bool emit_a = duo_emit_in_a(cpe ? na_v : na_u, cpe);
+    const bool writer = emit_a ? DO_A : DO_B;
+    if (writer && live) wv.st_begin(out);
 
     /* ---- U (or the mono channel) ---- */
     s.mean = cfg.mb;
@@ -386,7 +438,7 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
             duo_phase_na<W, OUT_STEREO, ROLE, false>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
         if (err_u == 0 && s.err != 0) err_chan = 1;
     }
-    if (DO_B && live) (void)wv.st_finish();
+    if (writer && live) (void)wv.st_finish();
     if (!DO_A || !live) return 0;
     if (s.err) {
         *frames_out = 0;
