@@ -353,3 +353,15 @@ class PacketDecoder:
 def NewPacketDecoder(config, device=0):
     """NewPacketDecoder (decoder.go:90): raises ErrConfig for bit depths outside {16,20,24,32}."""
     return PacketDecoder(config, device)
+
+
+def NewDecoder(source, device=0, window=4096):
+    """NewDecoder (decode.go:50-76): streaming façade over the batch path, see stream.py."""
+    from . import stream
+    return stream.NewDecoder(source, device=device, window=window)
+
+
+def FindALACTrack(data):
+    """internal/mp4 FindALACTrack (mp4.go:233-298) on a file in memory -> mp4.Track (cookie, offsets, sizes)."""
+    from . import mp4
+    return mp4.find_alac_track(data)
