@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""gpu_fuzz.py — one-off randomized parity sweep on the GPU: random frame lengths, depths, channel counts, signal
+profiles, batch sizes and wave widths, intact and corrupted packets, HIP path vs oracle through the C ABI.
+usage: python tools/gpu_fuzz.py [rounds] [seed]"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch  # noqa: F401  (one HIP runtime per process: torch first)
+pkg = importlib.import_module("saprobe-alac_amd")
+synth = importlib.import_module("saprobe-alac_amd.synth")
+from oracle import oracle
+from conftest import mutate_packets, pack_packets, assert_same_decode
+synth.build(); oracle.build()
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for r in range(rounds):
+    depth = int(rng.choice([16, 16, 16, 20, 24, 24, 32]))
+    ch = int(rng.choice([1, 2, 2, 2, 3, 6, 8]))
+    fl = int(rng.choice([int(rng.integers(1, 70)), int(rng.integers(70, 600)), int(rng.integers(600, 5000)), 4096, 352]))
+    prof = int(rng.choice([synth.PROFILE_MUSIC, synth.PROFILE_NOISE, synth.PROFILE_QUIET, synth.PROFILE_STRESS]))
+    n = int(rng.choice([1, 7, 64, 65, 200, 700]))
+    ppw = rng.choice(["", "64", "16", "2"])
+    if ppw:
+        os.environ["ALACGPU_PPW"] = str(ppw)
+    else:
+        os.environ.pop("ALACGPU_PPW", None)
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    b = synth.gen_batch(cfg, n, profile=prof, base_seed=int(rng.integers(1 << 30)), threads=8)
+    blob, offs, sizes = b.blob, b.offsets, b.sizes
+    if rng.integers(3) == 0:
+        blob, offs, sizes = pack_packets(mutate_packets(b, rng, n))
+    ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=8)
+    c = pkg.PacketConfig(FrameLength=fl, BitDepth=depth, NumChannels=ch, PB=cfg.pb, MB=cfg.mb, KB=cfg.kb,
+                         MaxRun=cfg.max_run, SampleRate=cfg.sample_rate)
+    with pkg.NewPacketDecoder(c, 0) as dec:
+        o = np.zeros(len(offs) + 1, np.uint64)
+        # host entry wants back-to-back packets: re-pack
+        pk = [bytes(blob[int(offs[i]):int(offs[i]) + int(sizes[i])]) for i in range(len(offs))]
+        o[1:] = np.cumsum([len(p) for p in pk])
+        out, fr, st = dec.decode_batch(np.frombuffer(b"".join(pk) + b"\0", np.uint8), o)
+    try:
+        assert_same_decode(cfg, ref, (out, fr, st), bpf, "round %d" % r)
+    except AssertionError as e:
+        bad += 1
+        print("MISMATCH depth %d ch %d fl %d prof %d n %d ppw %r: %s" % (depth, ch, fl, prof, n, ppw, e))
+print("%d rounds, %d mismatches" % (rounds, bad))
+sys.exit(1 if bad else 0)
