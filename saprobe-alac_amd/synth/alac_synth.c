@@ -74,6 +74,7 @@ static void bw_put(bitw* w, uint32_t val, uint32_t nbits) {
     uint32_t used = (uint32_t)(w->bitpos & 7);
     if (byte + 8 > w->cap) { /* need room for the widest spill */
         w->overflow = 1;
+        w->bitpos += nbits; /* keep counting: callers align with `while (bitpos & 7)` */
         return;
     }
     /* merge into a 40-bit big-endian window starting at `byte` */
@@ -602,8 +603,10 @@ static void* gen_worker(void* arg) {
 }
 
 size_t alac_synth_slot_bytes(const alacgpu_config* cfg) {
-    /* escape worst case + headers + FIL/DSE extras, rounded up */
-    size_t raw = (size_t)cfg->frame_length * cfg->num_channels * 6u;
+    /* worst case of the compressed form, which the stress profile may be told to keep however large it gets: an
+     * escape-coded sample (9 + chanBits <= 42 bits, shift byte included) or a regular one followed by an
+     * escape-coded zero-run length (<= 23 + 25 bits), so 9 bytes per sample; + headers + FIL/DSE extras */
+    size_t raw = (size_t)cfg->frame_length * cfg->num_channels * 9u;
     return (raw + 8u * 80u + 256u + 15u) & ~(size_t)15u;
 }
 

@@ -45,6 +45,8 @@ for r in range(rounds):
         assert_same_decode(cfg, ref, (out, fr, st), bpf, "round %d" % r)
     except AssertionError as e:
         bad += 1
-        print("MISMATCH depth %d ch %d fl %d prof %d n %d ppw %r: %s" % (depth, ch, fl, prof, n, ppw, e))
+        print("MISMATCH depth %d ch %d fl %d prof %d n %d ppw %r: %s" % (depth, ch, fl, prof, n, ppw, e), flush=True)
+    if r % 50 == 49:
+        print("round %d" % (r + 1), flush=True)
 print("%d rounds, %d mismatches" % (rounds, bad))
 sys.exit(1 if bad else 0)
