@@ -55,6 +55,11 @@
 /* 0 for x <= 0, 1 for x >= 1: one v_med3_i32 on the GPU */
 #define ALAC_CLAMP01(x) ((x) > 0 ? 1 : 0)
 #endif
+#ifndef ALAC_BFI
+/* bitwise select (a & m) | (b & ~m): one v_bfi_b32 on the GPU, opaque to the optimiser (it knows the masks here are
+ * all-ones or zero and turns the expression back into a compare and a select) */
+#define ALAC_BFI(m, a, b) ((((uint32_t)(a)) & (uint32_t)(m)) | (((uint32_t)(b)) & ~(uint32_t)(m)))
+#endif
 #ifndef ALAC_MAD24
 /* a * b + c for 24-bit a, b: one v_mad_i32_i24 on the GPU, opaque to the optimiser (a sum of such products written
  * plainly is re-associated into multiplies and a tree of adds: more instructions for latency nobody is waiting on) */
@@ -333,21 +338,21 @@ ALAC_DEV int32_t gol_step(W& wv, const Bits& bits, RegLane<W>& s, uint32_t size,
     int32_t del = (int32_t)(((hm ^ sg) - sg) & norun);
     const uint32_t o_pos = s.pos, o_mean = s.mean, o_zmode = s.zmode, o_zrem = s.zrem;
     s.pos = o_pos + ((pre + k + umin(vm1, 1u)) & okm); /* prefix + 1, then k bits (v >= 2) or k - 1 */
-    s.mean = (mean2 & okm) | (o_mean & ~okm);
+    s.mean = ALAC_BFI(okm, mean2, o_mean);
     s.zmode = o_zmode & ~okm;
     s.zrem = ALAC_SUBSAT(o_zrem, 1u);
     on_mask = next_on;
-    if (wv.any(rare != 0u)) {
-        if (rare != 0u) {
-            s.pos = o_pos;
-            s.mean = o_mean;
-            s.zmode = o_zmode;
-            s.zrem = o_zrem;
-            del = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns);
-            s.rd.reseek(wv, s.pos);
-            ns_live = s.err ? 0u : ns_live;
-            on_mask = (uint32_t)((int32_t)(i + 1u - ns_live) >> 31);
-        }
+    /* a plain divergent branch: one compare, one exec-mask save and a skip when no lane is in there (wrapping it
+     * in a wave-wide any() first only adds scalar instructions to every step) */
+    if (rare != 0u) {
+        s.pos = o_pos;
+        s.mean = o_mean;
+        s.zmode = o_zmode;
+        s.zrem = o_zrem;
+        del = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns);
+        s.rd.reseek(wv, s.pos);
+        ns_live = s.err ? 0u : ns_live;
+        on_mask = (uint32_t)((int32_t)(i + 1u - ns_live) >> 31);
     }
     s.rd.slide(wv, s.pos);
     return del;

@@ -46,6 +46,12 @@ __device__ __forceinline__ uint32_t alac_xad(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 #define ALAC_XAD(a, b, c) alac_xad((uint32_t)(a), (uint32_t)(b), (uint32_t)(c))
+__device__ __forceinline__ uint32_t alac_bfi(uint32_t m, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+#define ALAC_BFI(m, a, b) alac_bfi((uint32_t)(m), (uint32_t)(a), (uint32_t)(b))
 __device__ __forceinline__ int32_t alac_mad24(int32_t a, int32_t b, int32_t c) {
     int32_t r;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
