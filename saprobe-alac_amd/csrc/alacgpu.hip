@@ -688,17 +688,18 @@ namespace {
 /* upper bound on the waves of a batch: every key present may end in one partly filled wave */
 size_t max_waves(size_t n, uint32_t ppw) { return (n + ppw - 1) / ppw + std::min<size_t>(n, 18 * 18 + 8); }
 
-/* Packets per wave. A VALU instruction costs the SIMD the same 4 cycles whether 64 lanes or 8 are live, and one
- * wave per SIMD already saturates it (measured: two half-full waves per SIMD are 1.6x SLOWER than one full wave).
- * So waves are kept full while there are at least as many of them as SIMDs (256 CUs x 4); only a smaller batch is
- * spread over narrower waves, to use SIMDs that would otherwise idle. */
+/* Packets per wave. A VALU instruction costs the SIMD the same 4 cycles whether 64 lanes or 8 are live, so waves
+ * are kept full while there is at least one workgroup per CU (256); a smaller batch is spread over narrower waves to
+ * use CUs that would otherwise idle — but no further: a packet is a serial chain whose speed is highest when its
+ * wave pair has a CU to itself (4 096 stereo packets: 2.57 ms on 1 024 four-lane pairs, 2.19 ms on 256 sixteen-lane
+ * pairs; 32 768 packets: 2.63 ms on 1 024 half-full pairs, 2.43 ms on 512 full ones). */
 uint32_t pick_ppw(size_t n) {
     if (const char* e = getenv("ALACGPU_PPW")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 64) return (uint32_t)v;
     }
     uint32_t ppw = kWave;
-    while (ppw > 1 && n / ppw < 1024) ppw >>= 1;
+    while (ppw > 1 && n / ppw < 256) ppw >>= 1;
     return ppw;
 }
 
