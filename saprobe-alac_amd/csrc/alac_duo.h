@@ -43,7 +43,8 @@ namespace alac {
 #ifndef ALAC_DUO_CHUNK
 #define ALAC_DUO_CHUNK 16
 #endif
-constexpr uint32_t DUO_CHUNK = ALAC_DUO_CHUNK; /* steps per queue buffer (a multiple of 8) */
+constexpr uint32_t DUO_CHUNK = ALAC_DUO_CHUNK;
+ /* steps per queue buffer (a multiple of 8) */
 enum { ROLE_A = 0, ROLE_B = 1, ROLE_BOTH = 2 };
 
 /*

@@ -26,8 +26,15 @@
 #define ALAC_DEV __device__ __forceinline__
 #define ALAC_NOINLINE
 #define ALAC_MUL24(a, b) __mul24((int)(a), (int)(b))
-/* written so that instruction selection picks v_sad_u32 */
-#define ALAC_SAD(a, b, c) ((max((uint32_t)(a), (uint32_t)(b)) - min((uint32_t)(a), (uint32_t)(b))) + (uint32_t)(c))
+/* |a - b| + c in one instruction. As an expression (max - min + c) the compiler shares the max / min between the
+ * unrolled steps of a chunk and ends up with three or four instructions for most taps. */
+__device__ __forceinline__ uint32_t alac_sad(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#define ALAC_SAD(a, b, c) alac_sad((uint32_t)(a), (uint32_t)(b), (uint32_t)(c))
+
 __device__ __forceinline__ int32_t alac_sign_med3(int32_t x) {
     int32_t r;
     asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(x));
