@@ -223,6 +223,30 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
         }
         wv.st_step(); /* collective of wave A */
     };
+    /* steady-state groups of role B: UN unrolled steps. Long predictors and the wide writers (64-bit shift windows)
+     * take half groups, or registers run out. For the wide writers, what a group needs from HBM / L2 (the U samples
+     * of its frames, the 8-byte windows on their shift values) is requested one group AHEAD, into upre / spre, so
+     * that the load latency hides behind a whole group of taps (24-bit stereo: 4.65 -> 4.11 ms). The 16-bit writer
+     * asks for its U samples at the top of its own group: one dword per frame, first needed a whole step later, and
+     * the extra registers and moves of looking ahead cost it more than the wait (2.45 -> 2.62 ms). */
+    constexpr uint32_t UN = (NR <= ALAC_DUO_UN8_MAX && NARROW && (F16 || !LAST || RAW || EMIT_A)) ? 8u : 4u;
+    constexpr bool HBM_IN = LAST && !RAW && !EMIT_A; /* the writer runs here and reads the U tile / shift bytes */
+    constexpr bool AHEAD = HBM_IN && !F16;
+    int32_t upre[UN];
+    uint64_t spre[UN];
+    uint32_t pre_row = 0xffffffffu; /* first frame of the group upre / spre hold */
+    const uint32_t sstep_b = (CPE ? 2u : 1u) * sb;
+    const uint32_t steady_end = (n_it / CH) * CH; /* whole chunks end here */
+    auto prefetch_group = [&](uint32_t row0) {
+        pre_row = row0;
+#pragma unroll
+        for (uint32_t j = 0; j < UN; ++j) {
+            upre[j] = 0;
+            spre[j] = 0;
+            if (CPE) upre[j] = *wv.u_row(row0 + j);
+            if (merge_any) spre[j] = bits.window(shift_pos + (row0 + j) * sstep_b);
+        }
+    };
     /* B: samples of chunk c (UnpcBlock, predictor.go:45-684): out[0] = residual, warm-up up to na (:53-79),
      * copy (0) / delta (31) modes, then the adaptive taps */
     auto predict_chunk = [&](uint32_t c) {
@@ -234,21 +258,21 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             /* steady state, a whole chunk: straight-line code; residuals (LDS), U samples and shift values
              * (HBM/L2) are all requested up front and their latency hides behind the taps of the first steps;
              * the history shift becomes register renaming across the unrolled steps */
-            /* long predictors and the wide writers (64-bit shift windows): half chunks, or registers run out */
-            constexpr uint32_t UN = (NR <= ALAC_DUO_UN8_MAX && NARROW && (F16 || !LAST || RAW || EMIT_A)) ? 8u : 4u;
             auto groups = [&](auto wrap) {
 #pragma nounroll
                 for (uint32_t g = 0; g < CH; g += UN) {
+                    const uint32_t row0 = c * CH + g;
                     int32_t dv[UN], uv[UN];
                     uint64_t sv[UN];
+                    if (AHEAD && pre_row != row0) prefetch_group(row0); /* first steady group: nothing was ahead */
 #pragma unroll
                     for (uint32_t j = 0; j < UN; ++j) {
                         dv[j] = wv.rq_read(buf, g + j);
-                        uv[j] = 0;
-                        sv[j] = 0;
-                        if (CPE && !EMIT_A) uv[j] = *wv.u_row(c * CH + g + j);
-                        if (!EMIT_A && merge_any) sv[j] = bits.window(shift_pos + (c * CH + g + j) * sstep);
+                        uv[j] = AHEAD ? upre[j] : 0;
+                        sv[j] = AHEAD ? spre[j] : 0ull;
+                        if (HBM_IN && !AHEAD && CPE) uv[j] = *wv.u_row(row0 + j);
                     }
+                    if (AHEAD && row0 + 2u * UN <= steady_end) prefetch_group(row0 + UN);
 #pragma unroll
                     for (uint32_t j = 0; j < UN; ++j)
                         put(buf, g + j, c * CH + g + j, predict(dv[j], wrap), uv[j], sv[j]);
