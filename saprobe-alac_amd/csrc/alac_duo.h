@@ -31,7 +31,7 @@
 #include "alac_regular.h"
 
 #ifndef ALAC_DUO_UN8_MAX
-#define ALAC_DUO_UN8_MAX 8 /* longest predictor whose steady-state chunk is unrolled whole */
+#define ALAC_DUO_UN8_MAX 12 /* longest predictor whose steady-state groups are 8 steps (else 4) */
 #endif
 #ifndef ALAC_DUO_STAMP
 /* profiling build only (-DALAC_DUO_PROF in alacgpu.hip): time stamps around the parts of an iteration */
