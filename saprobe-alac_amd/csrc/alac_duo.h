@@ -229,7 +229,11 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
      * that the load latency hides behind a whole group of taps (24-bit stereo: 4.65 -> 4.11 ms). The 16-bit writer
      * asks for its U samples at the top of its own group: one dword per frame, first needed a whole step later, and
      * the extra registers and moves of looking ahead cost it more than the wait (2.45 -> 2.62 ms). */
-    constexpr uint32_t UN = (NR <= ALAC_DUO_UN8_MAX && NARROW && (F16 || !LAST || RAW || EMIT_A)) ? 8u : 4u;
+#ifndef ALAC_DUO_UN8_WIDE_MAX
+#define ALAC_DUO_UN8_WIDE_MAX 0 /* same for the wide writers (their groups also hold 64-bit shift windows) */
+#endif
+    constexpr uint32_t UN = (NARROW && (((F16 || !LAST || RAW || EMIT_A) && NR <= ALAC_DUO_UN8_MAX) ||
+                                        NR <= ALAC_DUO_UN8_WIDE_MAX)) ? 8u : 4u;
     constexpr bool HBM_IN = LAST && !RAW && !EMIT_A; /* the writer runs here and reads the U tile / shift bytes */
     constexpr bool AHEAD = HBM_IN && !F16;
     int32_t upre[UN];
