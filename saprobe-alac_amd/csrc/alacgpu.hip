@@ -5,14 +5,19 @@
  * predictor.go, matrix.go) with HIP kernels over a batch of independent packets. There is no host decode
  * path in this library: every decode entry launches the kernels.
  *
- * One decode = four launches on the handle's stream:
- *   alac_classify  one thread per packet: predictor-order class from the first element header (10 bytes read)
- *   alac_plan      one thread: class histogram -> packet/wave ranges (slow classes get the lowest block ids)
+ * One decode = these launches on the handle's stream:
+ *   alac_classify  one thread per packet: sort key from the first element header (a few bytes read)
+ *   alac_plan      one wavefront: key histogram -> packet / wave ranges (irregular keys, then the longest predictors)
  *   alac_scatter   one thread per packet: counting-sort scatter into the lane permutation
- *   alac_decode    one 64-lane wavefront per 64 same-class packets, lanes in lock step (alac_wave.h);
- *                  PCM is staged per lane in LDS and written back as whole 128-B lines.
- * HBM traffic per packet: compressed bytes in, PCM bytes out, plus the U-channel hand-off tile
- * (frame_length x 64 x int32 per wave, row-coalesced, written once and read once).
+ *   alac_scan      irregular packets, one wavefront per 64: status, frame count, where each channel starts
+ *   alac_decode    regular packets: a PAIR of wavefronts per 64 same-key packets (alac_duo.h): entropy wave and
+ *                  predictor / PCM wave, residuals through an LDS queue; PCM staged in LDS, written as 128-B lines
+ *   alac_task_classify / alac_plan / alac_scatter / alac_chan_decode   (> 2 channels) the same pair per 64
+ *                  (packet, channel) tasks the scan found, int32 rows
+ *   alac_interleave, alac_legacy   PCM of the scanned packets (frame order), whole-packet decoder for the rest
+ * HBM traffic per packet: compressed bytes in, PCM bytes out, plus the U-channel hand-off tile of stereo pairs
+ * ((frame_length + 1) x 64 x int32 per workgroup, row-coalesced, written once and read once) or the sample rows
+ * of the split pipeline.
  */
 #include <hip/hip_runtime.h>
 
@@ -118,8 +123,8 @@ constexpr uint32_t kFallbackSlots = 64;
 constexpr uint32_t kRingStride = 36; /* 32 ring dwords + 4: rows stay 16-byte aligned, lanes spread over banks */
 
 /* device-side launch plan, rebuilt by every decode */
-/* sort keys: 0..1023 regular packets (numU*32 + numV, alac_regular.h); 1024+c irregular packets of
- * predictor class c (alac_wave.h). A wave holds packets of ONE key. */
+/* sort keys: 0..1023 regular packets (numU*32 + numV, alac_regular.h); 1024 / 1025 irregular packets (below). A
+ * workgroup holds packets of ONE key. */
 constexpr uint32_t kKeys = 1024 + alac::NUM_CLASSES;
 constexpr uint32_t kKeyLegacy = 1024; /* decode_wave */
 constexpr uint32_t kKeyScan = 1025;   /* decode_wave<SCAN> + split pipeline */
@@ -219,7 +224,7 @@ struct GpuWave {
         flushed = wcnt;
         return wcnt;
     }
-    /* bitstream ring of the lean decoder: 32 dwords per lane, rows of kRingStride dwords (16-byte aligned) */
+    /* bitstream ring of the entropy wave: 32 dwords per lane, rows of kRingStride dwords (16-byte aligned) */
     ALAC_DEV void ring_write4(uint32_t slot, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
         /* (slot >> 2) * 4 lets the compiler see the 16-byte alignment: one ds_write_b128 */
         *reinterpret_cast<uint4*>(&s_ring[lane * kRingStride + (slot >> 2) * 4u]) = make_uint4(a, b, c, d);
