@@ -382,7 +382,11 @@ ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1
     /* D0 = |del|: what is left of it after the taps above. Signed and never wrapping: the taps take at most
      * sum(na - j) * 2^23 = 136 * 2^23 < 2^31 away from a value >= 0 */
     int32_t rem = (int32_t)(((uint32_t)del ^ sgnm) + nsg);
-    /* den_half - sum coef_j * (top - h_j), as one multiply-add chain over e_j = h_j - top */
+    /* den_half - sum coef_j * (top - h_j), as one multiply-add chain over e_j = h_j - top.
+     * The build runs with the pre-RA scheduler off (csrc/Makefile), so the instructions issue in THIS order: each
+     * tap's nine instructions together. Measured against the alternative of one operation at a time over all taps
+     * (independent instructions back to back): 2.45 ms vs 3.01 ms on the benchmark batch — with a partner wave on the
+     * SIMD filling the gaps, short live ranges matter more than the distance between dependent instructions. */
     int32_t acc = den_half;
 #pragma unroll
     for (int j = NR - 1; j >= 0; --j) {
