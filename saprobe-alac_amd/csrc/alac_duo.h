@@ -74,7 +74,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
     constexpr uint32_t CH = EMIT_A ? DUO_CHUNK / 2u : DUO_CHUNK;
     const uint32_t na = GEN ? na_rt : (uint32_t)NA;
     const uint32_t kb = cfg.kb;
-    const uint32_t wb = (1u << kb) - 1u;
+    const uint32_t wb = go_shl(1u, kb) - 1u; /* SetAGParams golomb.go:60: KB >= 32 gives all ones (KB is a cookie byte) */
     const uint32_t chan_shift = 32u - chan_bits;
     const int32_t den_half = den_shift ? (int32_t)(1u << (den_shift - 1u)) : 0;
     const uint32_t rnd_neg = (1u << den_shift) - 1u;

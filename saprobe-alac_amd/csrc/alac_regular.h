@@ -465,7 +465,7 @@ ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const Bits& bits, const uin
     s.pb = pb_local;
     const uint32_t my_ns = go ? ns : 0u;
     const uint32_t n_it = wv.max_u32(my_ns);
-    const uint32_t kb = cfg.kb, wb = (1u << kb) - 1u;
+    const uint32_t kb = cfg.kb, wb = go_shl(1u, kb) - 1u; /* golomb.go:60 */
     s.rd.start(wv, s.pos);
     uint32_t ns_live = my_ns;
     uint32_t on_mask = (uint32_t)((int32_t)(0u - ns_live) >> 31);

@@ -1,0 +1,109 @@
+"""Cross-check of the two CPU restatements of the reference: oracle/alac_oracle.c (C, round 1) against tests/goref.py
+(pure Python, round 2, written from the Go source without consulting the C file).
+
+    python tests/golden/crosscheck_goref.py [--packets 10000] [--seed N]
+
+Runs the committed golden vectors, then `--packets` synthetic packets (STRESS: random orders 0..31, random int16
+coefficients, random denShift / mixBits / mixRes / bytesShifted / modes, partial frames, FIL / DSE / missing END;
+plus MUSIC, QUIET and NOISE) over depth x channels x small frame lengths, and the same number of corrupted packets
+(bit flips, truncation, header damage, garbage). Status word, frame count and every PCM byte must agree.
+
+Known, documented deviation: a CPE mapped to the last output slot (only reachable when the element
+order does not match NumChannels) — the reference writes outside the frame and panics only on a full frame; the
+oracle and the kernels call it malformed. Such packets are counted and skipped here.
+"""
+import argparse
+import hashlib
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import goref  # noqa: E402
+from conftest import mutate_packets  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+synth = importlib.import_module("saprobe-alac_amd.synth")
+
+CONFIGS = [  # (frame_length, depth, channels, kb)
+    (64, 16, 2, 14), (48, 24, 2, 14), (40, 16, 1, 14), (32, 20, 2, 14), (32, 32, 2, 14), (24, 24, 8, 14), (24, 16, 6, 14),
+    (33, 24, 3, 14), (16, 32, 5, 14), (96, 16, 2, 14), (64, 32, 1, 14), (40, 20, 4, 14), (24, 24, 7, 14), (128, 24, 2, 14),
+    (64, 16, 2, 32), (64, 16, 2, 255), (48, 24, 1, 3), (40, 16, 2, 0),
+]
+PROFILES = [synth.PROFILE_STRESS] * 5 + [synth.PROFILE_MUSIC, synth.PROFILE_QUIET, synth.PROFILE_NOISE]
+
+
+def compare(cfg_o, cfg_g, packet):
+    st, frames, pcm = oracle.decode_packet(cfg_o, packet)
+    info = {}
+    g_pcm, g_frames, g_st = goref.decode_packet(cfg_g, packet, info=info)
+    if (st, frames, pcm) == (g_st, g_frames, g_pcm):
+        return "ok"
+    if st == 6 and info["cpe_last_slot"]:
+        return "cpe-last-slot"  # documented deviation, see module docstring
+    return "MISMATCH oracle (st %#x, frames %d, sha %s) goref (st %#x, frames %d, sha %s)" % (
+        st, frames, hashlib.sha256(pcm).hexdigest()[:12], g_st, g_frames, hashlib.sha256(g_pcm).hexdigest()[:12])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--packets", type=int, default=10000)
+    ap.add_argument("--seed", type=int, default=20261004)
+    args = ap.parse_args()
+    t0 = time.time()
+    bad = 0
+    g = json.load(open(os.path.join(HERE, "golden_packets.json")))
+    c = g["config_common"]
+    for v in g["vectors"]:
+        cfg_g = goref.PacketConfig(v["frame_length"], v["bit_depth"], v["num_channels"], c["pb"], c["mb"], c["kb"], c["max_run"])
+        pcm, fr, st = goref.decode_packet(cfg_g, bytes.fromhex(v["packet"]))
+        if (st, fr) != (v["status"], v["frames"]) or hashlib.sha256(pcm).hexdigest() != v["pcm_sha256"]:
+            bad += 1
+            print("golden vector", v["frame_length"], v["bit_depth"], v["num_channels"], v["index"], "MISMATCH")
+    print("golden_packets.json: %d vectors, %d mismatches" % (len(g["vectors"]), bad))
+
+    rng = np.random.default_rng(args.seed)
+    per = max(1, args.packets // (len(CONFIGS) * len(PROFILES)))
+    counts = {"ok": 0, "cpe-last-slot": 0}
+    statuses = {}
+    n_valid = n_mut = 0
+    for fl, depth, ch, kb in CONFIGS:
+        cfg_o = oracle.make_config(fl, depth, ch, kb=kb)
+        cfg_g = goref.PacketConfig(fl, depth, ch, 40, 10, kb, 255)
+        for pi, prof in enumerate(PROFILES):
+            if kb == 0 and prof != synth.PROFILE_STRESS:
+                continue
+            try:
+                b = synth.gen_batch(cfg_o, per, profile=prof, base_seed=args.seed + 977 * pi, threads=2)
+            except RuntimeError:
+                continue  # the encoder has no representation for this configuration (kb 0 with large residuals)
+            packets = [b.packet(i) for i in range(b.n)]
+            muts = mutate_packets(b, rng, per)
+            for is_mut, p in [(0, q) for q in packets] + [(1, q) for q in muts]:
+                r = compare(cfg_o, cfg_g, p)
+                if r in counts:
+                    counts[r] += 1
+                else:
+                    bad += 1
+                    print("fl %d depth %d ch %d kb %d profile %d %s: %s\n  packet %s" % (
+                        fl, depth, ch, kb, prof, "mutant" if is_mut else "valid", r, p.hex()))
+                st = oracle.decode_packet(cfg_o, p)[0]
+                statuses[st & 0xff] = statuses.get(st & 0xff, 0) + 1
+                n_valid += 1 - is_mut
+                n_mut += is_mut
+    print("synthetic: %d valid + %d corrupted packets: %d agree, %d skipped (CPE in the last slot), %d mismatches" % (
+        n_valid, n_mut, counts["ok"], counts["cpe-last-slot"], bad))
+    print("status codes seen (oracle): %s" % dict(sorted(statuses.items())))
+    print("%.1f s" % (time.time() - t0))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,220 @@
+"""Assembles the hand-built known-answer packets K5..K13 into tests/golden/kat2.json.
+
+This script only PACKS BITS: every field below was chosen by hand, every expected PCM byte string was worked out on
+paper from the reference source (tests/golden/kat_derivation.md holds the derivations, step by step, with the reference
+lines they follow) and is typed in here as a constant. Nothing in this file decodes anything; no decoder (oracle,
+goref, kernel) was used to produce the expectations. tests/test_oracle.py, tests/test_goref.py and
+tests/test_gpu_parity.py then require the C oracle, the Python transliteration and the HIP kernels to reproduce them.
+
+    python tests/golden/kat_build.py        # rewrites kat2.json
+"""
+import json
+import os
+
+
+class BitWriter:
+    def __init__(self):
+        self.bits = []
+
+    def put(self, value, n):
+        value &= (1 << n) - 1
+        for i in range(n - 1, -1, -1):
+            self.bits.append((value >> i) & 1)
+        return self
+
+    def raw(self, s):
+        self.bits += [int(c) for c in s if c in "01"]
+        return self
+
+    def align(self):
+        while len(self.bits) % 8:
+            self.bits.append(0)
+        return self
+
+    def hex(self):
+        self.align()
+        out = bytearray()
+        for i in range(0, len(self.bits), 8):
+            b = 0
+            for j in range(8):
+                b = (b << 1) | self.bits[i + j]
+            out.append(b)
+        return out.hex().upper()
+
+
+# static code used by most KATs: cookie MB=255 and pbFactor=0 keep the mean at 255, so m = 0, k = 1 and no zero run is
+# ever tested (255 << 2 >= 512): a residual is `nd` ones and a zero (nd <= 8), or nine ones and nd as a chanBits-bit
+# literal; nd = 2*del for del >= 0, -2*del - 1 for del < 0 (golomb.go:172-218; kat_derivation.md §0)
+def unary(bw, dels, chan_bits):
+    for d in dels:
+        nd = 2 * d if d >= 0 else -2 * d - 1
+        if nd <= 8:
+            bw.raw("1" * nd + "0")
+        else:
+            bw.raw("1" * 9).put(nd, chan_bits)
+
+
+def elem_header(bw, tag, partial=0, bs=0, escape=0, num_samples=None):
+    bw.put(tag, 3).put(0, 4).put(0, 12).put((partial << 3) | (bs << 1) | escape, 4)
+    if partial:
+        bw.put(num_samples, 32)
+
+
+def chan_header(bw, mode, den_shift, pb_factor, coefs):
+    bw.put(mode, 4).put(den_shift, 4).put(pb_factor, 3).put(len(coefs), 5)
+    for c in coefs:
+        bw.put(c, 16)
+
+
+def le(values, nbytes):
+    out = bytearray()
+    for v in values:
+        v &= (1 << (8 * nbytes)) - 1
+        out += v.to_bytes(nbytes, "little")
+    return out.hex().upper()
+
+
+def build():
+    kats = []
+
+    # ---- K5: 16-bit CPE, order 4 on both channels, negative mixRes (kat_derivation.md §K5) -----------------------
+    bw = BitWriter()
+    elem_header(bw, 1)
+    bw.put(2, 8).put(-3, 8)                         # mixBits 2, mixRes -3
+    chan_header(bw, 0, 1, 0, [3, -2, 1, 1])          # U
+    chan_header(bw, 0, 1, 0, [-1, 2, 0, 1])          # V
+    unary(bw, [50, 4, -3, 2, -4, 3, -40, 0, 100, -2], 17)
+    unary(bw, [3, 1, 1, -2, 3, -1, 2, 0, -3, 4], 17)
+    bw.put(7, 3)
+    lr = [56, 53, 61, 57, 60, 55, 59, 56, 60, 54, 53, 52, 26, 16, -43, -38, -2, -19, -92, -80]
+    kats.append({"name": "K5 CPE order 4 both signs, negative mixRes", "frame_length": 10, "bit_depth": 16,
+                 "num_channels": 2, "mb": 255, "packet": bw.hex(), "pcm": le(lr, 2)})
+
+    # ---- K6: 16-bit SCE, order 6 -----------------------------------------------------------------------------------
+    bw = BitWriter()
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 2, 0, [5, -3, 2, -1, 1, -2])
+    unary(bw, [10, 3, -2, 4, -1, 2, -3, 4, -3, -30, 2], 16)
+    bw.put(7, 3)
+    kats.append({"name": "K6 SCE order 6", "frame_length": 11, "bit_depth": 16, "num_channels": 1, "mb": 255,
+                 "packet": bw.hex(), "pcm": le([10, 13, 11, 15, 14, 16, 13, 13, 14, -14, -11], 2)})
+
+    # ---- K7: 3 channels: SCE order 8, then CPE with order 0 (U) and 31 (V), mixRes 0 ---------------------------------
+    bw = BitWriter()
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 3, 0, [8, -7, 6, -5, 4, -3, 2, -1])
+    unary(bw, [5, -1, 2, -2, 3, -3, 4, -4, 1, 3, -9, 2], 16)
+    elem_header(bw, 1)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 0, 0, [])
+    chan_header(bw, 0, 5, 0, list(range(1, 32)))     # numActive 31: 31 coefficient words are read and ignored
+    unary(bw, [1, -1, 2, -2, 3, -3, 4, -4, 0, 1, -1, 2], 17)
+    unary(bw, [100, 1, 1, 1, -2, -2, 3, 0, -4, 4, -1, 2], 17)
+    bw.put(7, 3)
+    c = [5, 4, 6, 4, 7, 4, 8, 4, 5, 14, -1, -2]
+    l = [1, -1, 2, -2, 3, -3, 4, -4, 0, 1, -1, 2]
+    r = [100, 101, 102, 103, 101, 99, 102, 102, 98, 102, 101, 103]
+    frames = []
+    for i in range(12):
+        frames += [l[i], r[i], c[i]]                 # SMPTE order L R C (decoder.go:58)
+    kats.append({"name": "K7 3-channel layout: SCE order 8, CPE orders 0 / 31", "frame_length": 12, "bit_depth": 16,
+                 "num_channels": 3, "mb": 255, "packet": bw.hex(), "pcm": le(frames, 2)})
+
+    # ---- K8: general predictor, order 2, int16 coefficient wrap in both directions ---------------------------------
+    bw = BitWriter()
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 15, 0, [32767, -32768])
+    unary(bw, [3, 2, -1, 2, -1, -3, 1, 0], 16)
+    bw.put(7, 3)
+    kats.append({"name": "K8 general order 2 with int16 wrap", "frame_length": 8, "bit_depth": 16, "num_channels": 1,
+                 "mb": 255, "packet": bw.hex(), "pcm": le([3, 5, 4, 4, 6, -1, -2, 5], 2)})
+
+    # ---- K9: mode != 0 double pass, adaptive Golomb with k = 1 and k = 2 (standard cookie) -------------------------
+    bw = BitWriter()
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 1, 1, 4, [2, -1, 1, -1])
+    bw.raw("111111110")      # s0: k=1, nd=8
+    bw.raw("111111110")      # s1: k=1, nd=8
+    bw.raw("10 10")          # s2: k=2, pre=1, v=2 -> n=4
+    bw.raw("110 0")          # s3: k=2, pre=2, v<2 -> n=6, one bit consumed
+    bw.raw("10 11")          # s4: k=2, pre=1, v=3 -> n=5
+    bw.raw("0 0")            # s5: k=2, pre=0, v<2 -> n=0
+    bw.raw("110 10")         # s6: k=2, pre=2, v=2 -> n=7
+    bw.raw("0 10")           # s7: k=2, pre=0, v=2 -> n=1
+    bw.put(7, 3)
+    kats.append({"name": "K9 mode 1 double pass, adaptive Golomb k=2", "frame_length": 8, "bit_depth": 16,
+                 "num_channels": 1, "mb": 10, "packet": bw.hex(), "pcm": le([4, 12, 22, 35, 45, 45, 58, 93], 2)})
+
+    # ---- K10: 24-bit CPE, bytesShifted 1, partial frame (6 of 8), general order 1 ----------------------------------
+    bw = BitWriter()
+    elem_header(bw, 1, partial=1, bs=1, num_samples=6)
+    bw.put(1, 8).put(1, 8)
+    chan_header(bw, 0, 2, 0, [3])
+    chan_header(bw, 0, 0, 0, [])
+    for b in [0x11, 0x22, 0x33, 0x44, 0x55, 0x66, 0x77, 0x88, 0x99, 0xAA, 0xBB, 0xCC]:
+        bw.put(b, 8)
+    unary(bw, [-2, 1, -1, 3, 0, -2], 17)
+    unary(bw, [1, -1, 2, 0, -3, 4], 17)
+    bw.put(7, 3)
+    pcm = "11FFFF22FEFF" "33FFFF440000" "55FFFF66FDFF" "770200880200" "99FEFFAA0100" "BB0100CCFDFF"
+    kats.append({"name": "K10 24-bit shift merge, partial frame, order 1", "frame_length": 8, "frames": 6,
+                 "bit_depth": 24, "num_channels": 2, "mb": 255, "packet": bw.hex(), "pcm": pcm})
+
+    # ---- K11: FIL (short and extended count), DSE with alignment, then a 20-bit SCE --------------------------------
+    bw = BitWriter()
+    bw.put(6, 3).put(2, 4).put(0xBEEF, 16)                    # FIL, count 2
+    bw.put(6, 3).put(15, 4).put(1, 8)                         # FIL, count 15 + 1 - 1 = 15
+    for i in range(15):
+        bw.put(0xA0 + i, 8)
+    bw.put(4, 3).put(0, 4).put(1, 1).put(3, 8).align()        # DSE, align flag, 3 bytes
+    bw.put(0xDEAD42, 24)
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 0, 0, [])
+    unary(bw, [1, -1, 2, -2, 3, -3], 20)
+    bw.put(7, 3)
+    kats.append({"name": "K11 FIL + DSE prefix, 20-bit SCE", "frame_length": 6, "bit_depth": 20, "num_channels": 1,
+                 "mb": 255, "packet": bw.hex(), "pcm": "100000F0FFFF200000E0FFFF300000D0FFFF"})
+
+    # ---- K12: 32-bit CPE, bytesShifted 2, negative mixRes ----------------------------------------------------------
+    bw = BitWriter()
+    elem_header(bw, 1, bs=2)
+    bw.put(3, 8).put(-5, 8)
+    chan_header(bw, 0, 0, 0, [])
+    chan_header(bw, 0, 0, 0, [])
+    for w in [0x1234, 0xABCD, 0x0001, 0xFFFF, 0x8000, 0x7FFF, 0x0F0F, 0xF0F0]:
+        bw.put(w, 16)
+    unary(bw, [3, -3, 4, -1], 17)
+    unary(bw, [-2, 4, 1, -4], 17)
+    bw.put(7, 3)
+    pcm = "34120000CDAB0200" "01000400FFFF0000" "00800600FF7F0500" "0F0FF9FFF0F0FDFF"
+    kats.append({"name": "K12 32-bit shift merge (2 bytes), negative mixRes", "frame_length": 4, "bit_depth": 32,
+                 "num_channels": 2, "mb": 255, "packet": bw.hex(), "pcm": pcm})
+
+    # ---- K13: 24-bit CPE escape element (chanBits > 16 path) -------------------------------------------------------
+    bw = BitWriter()
+    elem_header(bw, 1, escape=1)
+    for hi, lo in [(0x1234, 0x56), (0xFFFF, 0xFF), (0x8000, 0x00), (0x7FFF, 0xFF), (0x0000, 0x01), (0x00FF, 0x00)]:
+        bw.put(hi, 16).put(lo, 8)
+    bw.put(7, 3)
+    kats.append({"name": "K13 24-bit CPE escape", "frame_length": 3, "bit_depth": 24, "num_channels": 2, "mb": 255,
+                 "packet": bw.hex(), "pcm": "563412FFFFFF000080FFFF7F01000000FF00"})
+    return kats
+
+
+def main():
+    out = {"_source": "hand-built packets; expected PCM derived on paper from the reference source in "
+                      "tests/golden/kat_derivation.md (no decoder was run to produce it)",
+           "config_common": {"pb": 40, "kb": 14, "max_run": 255}, "vectors": build()}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat2.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path, len(out["vectors"]), "vectors")
+
+
+if __name__ == "__main__":
+    main()

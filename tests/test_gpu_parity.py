@@ -33,6 +33,21 @@ def test_known_answer_packets_on_gpu(pkg):
             assert (f.SampleRate, f.BitDepth, f.Channels) == (44100, 16, v["num_channels"])
 
 
+def test_hand_derived_predictor_and_matrix_packets_on_gpu(pkg):
+    """K5..K13 (tests/golden/kat_derivation.md) through DecodePacket on the GPU."""
+    k = json.load(open(os.path.join(HERE, "golden", "kat2.json")))
+    c = k["config_common"]
+    for v in k["vectors"]:
+        cfg = pkg.PacketConfig(FrameLength=v["frame_length"], BitDepth=v["bit_depth"], NumChannels=v["num_channels"],
+                               PB=c["pb"], MB=v["mb"], KB=c["kb"], MaxRun=c["max_run"])
+        with pkg.NewPacketDecoder(cfg) as dec:
+            pcm = dec.DecodePacket(bytes.fromhex(v["packet"]))
+            assert pcm.hex().upper() == v["pcm"].upper(), v["name"]
+            # the same packet inside a batch of copies (regular path: full waves, same key)
+            res = dec.DecodePackets([bytes.fromhex(v["packet"])] * 70)
+            assert all(r == pcm for r in res), v["name"]
+
+
 def test_golden_packets_on_gpu(pkg):
     g = json.load(open(os.path.join(HERE, "golden", "golden_packets.json")))
     c = g["config_common"]
@@ -78,14 +93,16 @@ def test_batch_matches_oracle(pkg, oracle, synth, helpers, gpu_decoder_factory, 
 
 
 @pytest.mark.parametrize("depth,ch,fl,kb", [(16, 2, 256, 14), (24, 2, 128, 14), (16, 1, 64, 14), (24, 8, 32, 14),
-                                            (20, 3, 50, 14), (32, 2, 64, 14), (16, 2, 256, 0), (16, 2, 8, 255)])
+                                            (20, 3, 50, 14), (32, 2, 64, 14), (16, 2, 256, 0), (16, 2, 8, 255),
+                                            (16, 2, 256, 32), (16, 2, 256, 255), (24, 5, 64, 40)])
 def test_corrupt_packets_match_oracle_and_do_not_poison_the_batch(pkg, oracle, synth, helpers, gpu_decoder_factory,
                                                                   depth, ch, fl, kb):
     cfg = oracle.make_config(fl, depth, ch, kb=kb)
     bpf = ch * oracle.bytes_per_sample(depth)
     rng = np.random.default_rng(99 + depth + ch + kb)
     with gpu_decoder_factory(cfg) as dec:
-        b = synth.gen_batch(cfg, 64, profile=synth.PROFILE_MUSIC, threads=8)
+        # KB >= 32 (a cookie byte, untrusted): zero runs (QUIET) are where WB = (1 << KB) - 1 matters (golomb.go:60,227)
+        b = synth.gen_batch(cfg, 64, profile=synth.PROFILE_QUIET if kb >= 32 else synth.PROFILE_MUSIC, threads=8)
         good = [b.packet(i) for i in range(b.n)]
         bad = helpers.mutate_packets(b, rng, 700)
         mixed = []

@@ -25,13 +25,19 @@ def test_lane_matches_oracle_on_valid_streams(oracle, synth, lane_sim, helpers, 
 
 @pytest.mark.parametrize("depth,ch,fl,kb", [(16, 2, 256, 14), (24, 2, 128, 14), (16, 1, 64, 14), (24, 8, 32, 14),
                                             (20, 3, 50, 14), (32, 2, 64, 14), (16, 5, 33, 14), (16, 2, 256, 0),
-                                            (24, 6, 16, 3), (16, 2, 8, 255), (32, 8, 5, 14)])
+                                            (24, 6, 16, 3), (16, 2, 8, 255), (32, 8, 5, 14), (16, 2, 256, 32),
+                                            (16, 2, 256, 255), (24, 5, 64, 40)])
 def test_lane_matches_oracle_on_corrupt_packets(oracle, synth, lane_sim, helpers, depth, ch, fl, kb):
     cfg = oracle.make_config(fl, depth, ch, kb=kb)
     bpf = ch * oracle.bytes_per_sample(depth)
     rng = np.random.default_rng(depth * 1000 + ch * 10 + kb)
-    for prof in (synth.PROFILE_MUSIC, synth.PROFILE_STRESS):
+    # QUIET: zero runs, whose multiplier is masked with WB = (1 << KB) - 1 (golomb.go:60,227): KB >= 32 must give all ones
+    for prof in (synth.PROFILE_MUSIC, synth.PROFILE_STRESS, synth.PROFILE_QUIET):
         b = synth.gen_batch(cfg, 48, profile=prof, threads=4)
+        if kb >= 32:  # the intact packets too: they reach the lean wave-pair path (fl > 32) with KB >= 32
+            ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=4)
+            helpers.assert_same_decode(cfg, ref, lane_sim(cfg, b.blob, b.offsets, b.sizes, variant=-1), bpf, "kb %d" % kb)
+            assert prof == synth.PROFILE_STRESS or fl <= 32 or (ref[2] == 0).all()
         blob, offs, sizes = helpers.pack_packets(helpers.mutate_packets(b, rng, 400))
         ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=4)
         for variant in (-1, -2, 0, 3):

@@ -33,6 +33,33 @@ def test_known_answer_packets(oracle, vec):
     assert pcm.hex().upper() == vec["pcm"].upper()
 
 
+def _kat2():
+    return json.load(open(os.path.join(HERE, "golden", "kat2.json")))
+
+
+@pytest.mark.parametrize("vec", _kat2()["vectors"], ids=lambda v: v["name"].split()[0])
+def test_hand_derived_predictor_and_matrix_packets(oracle, vec):
+    """K5..K13 (tests/golden/kat_derivation.md): hand-derived answers that reach unpcBlock4/6/8, unpcBlockGeneral with
+    the int16 wrap, numActive 0 / 31, the mode != 0 double pass, negative mixRes, the 24/32-bit shift merge, partial
+    frames, FIL / DSE, the 3-channel layout, 20-bit output and the escape element's chanBits > 16 path."""
+    c = _kat2()["config_common"]
+    cfg = oracle.make_config(vec["frame_length"], vec["bit_depth"], vec["num_channels"], c["pb"], vec["mb"], c["kb"],
+                             c["max_run"])
+    st, frames, pcm = oracle.decode_packet(cfg, bytes.fromhex(vec["packet"]))
+    assert st == 0
+    assert frames == vec.get("frames", vec["frame_length"])
+    assert pcm.hex().upper() == vec["pcm"].upper()
+
+
+def test_kat2_json_is_what_kat_build_packs():
+    """kat2.json is the output of tests/golden/kat_build.py (a bit packer + typed-in expectations), nothing else."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kat_build", os.path.join(HERE, "golden", "kat_build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.build() == _kat2()["vectors"]
+
+
 def test_golden_packets(oracle):
     g = _golden()
     c = g["config_common"]
