@@ -70,8 +70,10 @@ typedef enum alacgpu_code {
     ALACGPU_ERR_INVALID_HEADER     = 3, /* ErrInvalidHeader      internal/alac/errors.go:28 */
     ALACGPU_ERR_INVALID_SHIFT      = 4, /* ErrInvalidShift       internal/alac/errors.go:29 */
     ALACGPU_ERR_UNSUPPORTED_ELEMENT= 5, /* ErrUnsupportedElement internal/alac/errors.go:27 */
-    ALACGPU_ERR_MALFORMED          = 6  /* input on which the Go reference panics (slice bounds);
+    ALACGPU_ERR_MALFORMED          = 6, /* input on which the Go reference panics (slice bounds);
                                            it has no defined result there, we return a status */
+    ALACGPU_ERR_RANGE              = 7  /* batch entries only: the packet's offset / size does not lie inside the
+                                           blob (no reference counterpart: a Go slice cannot be out of range) */
 } alacgpu_code;
 
 typedef enum alacgpu_ctx {
@@ -102,11 +104,11 @@ typedef enum alacgpu_stage {
 #define ALACGPU_E_HIP      -3  /* HIP runtime failure; see alacgpu_last_error */
 #define ALACGPU_E_DECODE   -4  /* alacgpu_decode_packet only: packet failed, *status_out holds the word */
 
-/* Every packet in a device-resident blob must be followed by at least this many
- * zero bytes (the reference pads each packet with 4, bitbuffer.go:33; the kernel's
- * bitstream ring is refilled in 16-byte blocks ahead of the read position). Packet starts need no alignment
- * (16 bytes is what alacgpu_decode_batch produces when it re-packs host input). */
-#define ALACGPU_PACKET_PAD 64
+/* Packets may lie DENSELY in a blob, back to back and at any alignment — an mdat as it is in the file
+ * (internal/mp4/mp4.go:382-420). The kernels treat every byte behind a packet's last one as zero (the reference pads
+ * each packet with 4 zero bytes, bitbuffer.go:33) and never touch memory outside [blob, blob + blob_bytes) rounded out
+ * to 4-byte words. Round 1 required 64 zero bytes behind every packet; padding is harmless but no longer needed. */
+#define ALACGPU_PACKET_PAD 0
 
 typedef struct alacgpu_decoder alacgpu_decoder;
 
@@ -130,22 +132,29 @@ int alacgpu_decode_packet(alacgpu_decoder* dec, const uint8_t* packet, size_t pa
                           uint8_t* out, size_t out_cap, size_t* out_len, int32_t* status_out);
 
 /*
- * DecodePackets, host buffers. Packet i is blob[offsets[i] .. offsets[i+1]).
+ * DecodePackets, host buffers. Packet i is blob[offsets[i] .. offsets[i+1]) (dense, e.g. a whole mdat).
  * PCM of packet i is written at out + i*out_stride (out_stride >= frame bytes);
  * frames_out[i] = the packet's sample-frame count (0 on failure), status[i] = status word.
  * A failing packet leaves its output slot unspecified and does not affect others.
+ * The batch is cut into chunks that are uploaded, decoded and downloaded on three streams at once; the bytes go to
+ * the device as they are. Pageable memory is staged through pinned buffers by a few copy threads
+ * (ALACGPU_COPY_THREADS); blob / out / frames_out / status that the caller allocated with hipHostMalloc or registered
+ * with hipHostRegister are transferred in place. Blocking: returns when everything is in the caller's buffers.
  */
 int alacgpu_decode_batch(alacgpu_decoder* dec, const uint8_t* blob, const uint64_t* offsets,
                          size_t n_packets, uint8_t* out, size_t out_stride,
                          uint32_t* frames_out, int32_t* status);
 
 /*
- * DecodePackets, device-resident (the benchmark path). All pointers are device
- * pointers on the handle's device. Packet i is d_blob[d_offsets[i] .. +d_sizes[i])
- * followed by >= ALACGPU_PACKET_PAD zero bytes. Asynchronous on the handle's
- * stream unless sync != 0.
+ * DecodePackets, device-resident (the benchmark path). All pointers are device pointers on the handle's device.
+ * Packet i is d_blob[d_offsets[i] .. +d_sizes[i]); d_sizes may be NULL, then d_offsets has n_packets+1 entries and
+ * packet i ends where packet i+1 starts. blob_bytes = readable bytes at d_blob: a packet that does not lie inside
+ * [0, blob_bytes) gets status ALACGPU_ERR_RANGE and is not read. Asynchronous on the handle's stream
+ * (alacgpu_stream()) unless sync != 0: the inputs must be complete, or ordered on that stream, before the call, and
+ * the outputs are complete after alacgpu_synchronize() (the stream is non-blocking: it does not order against the
+ * legacy default stream or torch's current stream by itself).
  */
-int alacgpu_decode_batch_device(alacgpu_decoder* dec, const uint8_t* d_blob,
+int alacgpu_decode_batch_device(alacgpu_decoder* dec, const uint8_t* d_blob, size_t blob_bytes,
                                 const uint64_t* d_offsets, const uint32_t* d_sizes,
                                 size_t n_packets, uint8_t* d_out, size_t out_stride,
                                 uint32_t* d_frames_out, int32_t* d_status, int sync);
@@ -154,11 +163,11 @@ int alacgpu_decode_batch_device(alacgpu_decoder* dec, const uint8_t* d_blob,
  * batch entries; exposed so callers can pre-size before timing). */
 int alacgpu_reserve(alacgpu_decoder* dec, size_t n_packets);
 
-/* Time of the last decode kernel launch on this handle in milliseconds, measured with
- * HIP events on the handle's stream (valid after a sync). Used by bench.py's roofline. */
+/* Duration of the last decode on this handle in milliseconds: HIP events on the handle's stream around ALL the
+ * kernels of the decode, the sort pre-pass included (valid after a sync). Used by bench.py's roofline. */
 int alacgpu_last_kernel_ms(alacgpu_decoder* dec, float* ms);
 
-/* Per-launch kernel durations: every decode launch is bracketed by a HIP event pair on the handle's
+/* Per-decode durations: every decode (all its kernels) is bracketed by a HIP event pair on the handle's
  * stream (ring of 64). alacgpu_kernel_times synchronizes the stream and returns the durations of the
  * min(max_n, launches since reset, 64) most recent launches, oldest first. */
 int alacgpu_timing_reset(alacgpu_decoder* dec);

@@ -34,7 +34,7 @@ __all__ = [
     "ErrConfig", "ErrDecode", "AlacError", "build", "lib", "lib_path",
 ]
 
-PACKET_PAD = 64  # ALACGPU_PACKET_PAD
+PACKET_PAD = 0  # ALACGPU_PACKET_PAD: blobs are dense since 0.3.0
 
 
 # ---- errors: errors.go:22-34 and internal/alac/errors.go:24-33 -------------------------------------
@@ -70,9 +70,10 @@ ErrBitstreamOverrun = "alac: bitstream overrun"
 ErrSampleOverrun = "alac: sample count exceeds buffer"
 ErrBitDepth = "alac: unsupported bit depth"
 ErrMalformed = "alac: malformed packet (the reference panics)"
+ErrRange = "alac: packet outside the blob"
 
 _CODE_SENTINEL = {1: ErrBitstreamOverrun, 2: ErrSampleOverrun, 3: ErrInvalidHeader, 4: ErrInvalidShift,
-                  5: ErrUnsupportedElement, 6: ErrMalformed}
+                  5: ErrUnsupportedElement, 6: ErrMalformed, 7: ErrRange}
 _CTX = {0: None, 1: "SCE/LFE", 2: "CPE", 3: "DSE", 4: "FIL"}
 _STAGE = {0: None, 1: "entropy decode", 2: "entropy decode U", 3: "entropy decode V"}
 
@@ -180,9 +181,9 @@ _EXPORTS = {
                                              ctypes.POINTER(ctypes.c_int32)]),
     "alacgpu_decode_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                             ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
-    "alacgpu_decode_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                                   ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
-                                                   ctypes.c_void_p, ctypes.c_int]),
+    "alacgpu_decode_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "alacgpu_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     "alacgpu_last_kernel_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
     "alacgpu_timing_reset": (ctypes.c_int, [ctypes.c_void_p]),
@@ -301,7 +302,7 @@ class PacketDecoder:
         offsets = np.zeros(n + 1, dtype=np.uint64)
         if n:
             offsets[1:] = np.cumsum([len(p) for p in packets], dtype=np.uint64)
-        blob = np.frombuffer(b"".join(packets) + b"\0", dtype=np.uint8)
+        blob = np.frombuffer(b"".join(packets) or b"\0", dtype=np.uint8)
         out, frames, status = self.decode_batch(blob, offsets)
         bpf = self.config.NumChannels * bytes_per_sample(self.config.BitDepth)
         res = []
@@ -323,10 +324,13 @@ class PacketDecoder:
                                                   stride, frames.ctypes.data, status.ctypes.data))
         return out, frames, status
 
-    def decode_batch_device(self, d_blob, d_offsets, d_sizes, n, d_out, out_stride, d_frames, d_status, sync=True):
-        """alacgpu_decode_batch_device: raw device pointers (ints), e.g. torch tensors' data_ptr()."""
-        _check(self._lib.alacgpu_decode_batch_device(self._h, d_blob, d_offsets, d_sizes, n, d_out, out_stride,
-                                                     d_frames, d_status, 1 if sync else 0))
+    def decode_batch_device(self, d_blob, blob_bytes, d_offsets, d_sizes, n, d_out, out_stride, d_frames, d_status,
+                            sync=True):
+        """alacgpu_decode_batch_device: raw device pointers (ints), e.g. torch tensors' data_ptr(); blob_bytes =
+        readable bytes at d_blob (packets may lie densely); d_sizes may be None (offsets then has n+1 entries).
+        The handle's stream does not order against torch's: synchronize the inputs first."""
+        _check(self._lib.alacgpu_decode_batch_device(self._h, d_blob, blob_bytes, d_offsets, d_sizes, n, d_out,
+                                                     out_stride, d_frames, d_status, 1 if sync else 0))
 
     def reserve(self, n_packets):
         _check(self._lib.alacgpu_reserve(self._h, n_packets))

@@ -55,8 +55,8 @@ enum { ROLE_A = 0, ROLE_B = 1, ROLE_BOTH = 2 };
  * mode (per lane) != 0: the delta pre-pass of decoder.go:307-309 runs on the residual stream first (split
  * pipeline only: regular packets have mode 0).
  */
-template <class W, int NA, int OUT, int ROLE, bool F16, bool NARROW, bool EA>
-ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
+template <class W, class B, int NA, int OUT, int ROLE, bool F16, bool NARROW, bool EA>
+ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
                         uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
                         uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb, uint32_t mode) {
     constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
@@ -73,7 +73,9 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
     constexpr bool DO_EMIT = EMIT_A ? DO_A : DO_B;
     constexpr uint32_t CH = EMIT_A ? DUO_CHUNK / 2u : DUO_CHUNK;
     const uint32_t na = GEN ? na_rt : (uint32_t)NA;
-    const uint32_t kb = cfg.kb;
+    uint32_t kb = cfg.kb;
+    ALAC_OWN_REG(kb); /* its own register: cfg is an 8-dword kernel-argument tuple that would otherwise be pulled out
+                         of its spill slot, whole, in every step of the entropy loop (8 v_readlane per step) */
     const uint32_t wb = go_shl(1u, kb) - 1u; /* SetAGParams golomb.go:60: KB >= 32 gives all ones (KB is a cookie byte) */
     const uint32_t chan_shift = 32u - chan_bits;
     const int32_t den_half = den_shift ? (int32_t)(1u << (den_shift - 1u)) : 0;
@@ -211,7 +213,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             if (i < n_it) { /* scalar: rows past n_it do not exist in the tile */
                 sq_v[j] = wv.rq_read(buf, CH + j);
                 if (CPE) u_v[j] = *wv.u_row(i);
-                if (merge_any) sw_v[j] = bits.window(shift_pos + i * sstep_a);
+                if (merge_any) sw_v[j] = bits.window_raw(shift_pos + i * sstep_a);
             }
         }
     };
@@ -248,7 +250,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             upre[j] = 0;
             spre[j] = 0;
             if (CPE) upre[j] = *wv.u_row(row0 + j);
-            if (merge_any) spre[j] = bits.window(shift_pos + (row0 + j) * sstep_b);
+            if (merge_any) spre[j] = bits.window_raw(shift_pos + (row0 + j) * sstep_b);
         }
     };
     /* B: samples of chunk c (UnpcBlock, predictor.go:45-684): out[0] = residual, warm-up up to na (:53-79),
@@ -311,7 +313,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
             else if (i <= na || (GEN && na == 31)) o = sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
             else o = predict(del, wrap_yes{});
             put(buf, j, i, o, (CPE && !EMIT_A) ? *wv.u_row(i) : 0,
-                (!EMIT_A && merge_any) ? bits.window(shift_pos + i * sstep) : 0ull);
+                (!EMIT_A && merge_any) ? bits.window_raw(shift_pos + i * sstep) : 0ull);
             if (LAST && !EMIT_A) wv.st_step();
         }
     };
@@ -349,23 +351,23 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const Bits& bits, RegLane<W>& 
 ALAC_DEV constexpr bool duo_emit_in_a(uint32_t na, bool cpe) { return !cpe && na >= 5u && na <= 16u; }
 
 /* the order switch is scalar: NA is wave-uniform by construction of the waves. Role A never looks at the order. */
-template <class W, int OUT, int ROLE, bool F16, bool NARROW = true>
-ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bits, RegLane<W>& s, uint32_t size,
+template <class W, int OUT, int ROLE, bool F16, bool NARROW = true, class B>
+ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits, RegLane<W>& s, uint32_t size,
                            uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
                            int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb, uint32_t mode = 0u) {
 #define ALAC_DUO_CASE(N)                                                                                              \
     case N:                                                                                                           \
-        duo_phase<W, N, OUT, ROLE, F16, NARROW, CAN_EA && duo_emit_in_a(N, OUT == OUT_STEREO)>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, \
+        duo_phase<W, B, N, OUT, ROLE, F16, NARROW, CAN_EA && duo_emit_in_a(N, OUT == OUT_STEREO)>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, \
                                                                        den_shift, chan_bits, mix_res, mix_sh, na,     \
                                                                        shift_pos, sb, mode);                          \
         break;
     constexpr bool CAN_EA = OUT == OUT_STEREO || OUT == OUT_MONO; /* phases that write PCM */
     if (ROLE == ROLE_A) {
         if (CAN_EA && duo_emit_in_a(na, OUT == OUT_STEREO))
-            duo_phase<W, 0, OUT, ROLE, F16, NARROW, true>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
+            duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, true>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
                                                           mix_res, mix_sh, na, shift_pos, sb, mode);
         else
-            duo_phase<W, 0, OUT, ROLE, F16, NARROW, false>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
+            duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, false>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
                                                            mix_res, mix_sh, na, shift_pos, sb, mode);
         return;
     }
@@ -387,7 +389,7 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bi
         ALAC_DUO_CASE(15)
         ALAC_DUO_CASE(16)
         default:
-            duo_phase<W, 0, OUT, ROLE, F16, NARROW, false>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
+            duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, false>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
                                                            mix_res, mix_sh, na, shift_pos, sb, mode);
             break;
     }
@@ -402,9 +404,9 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const Bits& bi
  */
 template <class W, int ROLE>
 ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
-                                    uint8_t* out, uint32_t* frames_out) {
+                                    uint32_t avail, uint8_t* out, uint32_t* frames_out) {
     constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
-    const Bits bits{pkt, size};
+    const BitsT<false> bits{pkt, size, avail}; /* regular packets hold at least 12 bytes (classify_regular) */
     const bool cpe = cfg.num_channels == 2;
     const uint32_t na_u = key >> 5, na_v = key & 31u;
 

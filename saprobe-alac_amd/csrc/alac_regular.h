@@ -74,6 +74,10 @@
  * (written as a product the compiler turns multiplications by 2, 4, 8 into two shifts and a subtraction) */
 #define ALAC_MSUB24(acc, a, c) ((int32_t)(acc) - (int32_t)(a) * (int32_t)(c))
 #endif
+#ifndef ALAC_OWN_REG
+/* gives a wave-uniform value a register of its own (opaque copy) on the GPU */
+#define ALAC_OWN_REG(x) ((void)0)
+#endif
 #ifndef ALAC_MULU24
 /* exact when both operands fit 24-bit unsigned: v_mul_u32_u24 / v_mad_u32_u24 on the GPU */
 #define ALAC_MULU24(a, b) ((uint32_t)(a) * (uint32_t)(b))
@@ -89,11 +93,11 @@ constexpr uint32_t NUM_KEYS = 1025;
 ALAC_DEV bool regular_order(uint32_t na) { return na <= 16 || na == 31; }
 
 /* Sort key of a packet; no entropy decoding, reads only the element header. */
-ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32_t size) {
+ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32_t size, uint32_t avail) {
     if (cfg.num_channels > 2 || cfg.aligned16 == 0 || cfg.kb == 0 ||
         cfg.frame_length > 65536u || cfg.frame_length <= 32u)
         return KEY_IRREGULAR;
-    const Bits bits{pkt, size};
+    const Bits bits{pkt, size, avail};
     if (size < 12) return KEY_IRREGULAR;
     const uint32_t tag = bits.get(0, 3);
     const bool cpe = cfg.num_channels == 2;
@@ -126,9 +130,11 @@ ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32
         pos += 16u + 16u * nv;
     }
     /* header and shift block must be wholly inside the packet and the entropy stream must start inside it
-     * (anything else is an error or panic case: decode_wave reports those) */
+     * (anything else is an error or panic case: decode_wave reports those); with shift bytes, eight bytes of entropy
+     * stream behind them keep the lean decoder's 8-byte windows on the shift values inside the packet
+     * (Bits::window_raw) */
     const uint64_t ent = (uint64_t)pos + (uint64_t)bs * 8u * (cpe ? 2u : 1u) * ns;
-    if ((ent >> 3) >= size) return KEY_IRREGULAR;
+    if ((ent >> 3) >= size || (bs != 0 && (ent >> 3) + 8u > size)) return KEY_IRREGULAR;
     return nu * 32u + nv;
 }
 
@@ -138,13 +144,17 @@ ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32
  * schedule (every 4th step): tick() first commits the block whose global load was issued 4 steps earlier, then
  * issues the next one. So no step ever waits on an HBM/L2 round trip: the data a step needs left memory at
  * least four steps ago, and each packet byte is fetched from L2 exactly once. A plain step consumes <= 32 bits,
- * so 4 dwords per 4 steps sustain it (reseek() covers the slow path); start() prefills 16 dwords. Loads stay inside size +
- * ALACGPU_PACKET_PAD; positions past size*8 + 66 bits are never decoded here. */
+ * so 4 dwords per 4 steps sustain it (reseek() covers the slow path); start() prefills 16 dwords.
+ * Dense blob (see Bits): blocks that lie wholly inside the packet are loaded as they are (one global_load_dwordx4);
+ * a block that reaches past the packet's last byte takes tail4(): aligned dwords that hold at least one packet byte
+ * are fetched (they cannot leave the blob's pages), the neighbour's bytes in them are cleared, and dwords wholly
+ * behind the packet are zeros without a fetch — the reference's zero pad (bitbuffer.go:33), as far out as anyone looks. */
 template <class W>
 struct RingRd {
     const uint32_t* base; /* packet start rounded down to a dword */
     uint32_t bias;        /* stream bit 0 is bit `bias` of base[0] */
-    uint32_t limit;       /* first dword index that may not be loaded */
+    uint32_t end_b;       /* first byte, counted from base, that is not packet data */
+    uint32_t full;        /* dwords [0, full) of base lie wholly inside the packet */
     uint32_t w0, w1, w2, widx;
     uint32_t fill;        /* ring holds dwords [fill-32, fill); multiple of 4 */
     uint32_t p0, p1, p2, p3;
@@ -155,15 +165,32 @@ struct RingRd {
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(pkt) & 3u);
         base = reinterpret_cast<const uint32_t*>(pkt - mis);
         bias = mis * 8u;
-        limit = ((bias >> 3) + size + ALACGPU_PACKET_PAD - 16u) >> 2; /* a 16-byte block starting below it stays inside the pad */
+        end_b = size ? mis + size : 0u; /* a lane without a packet keeps nothing of what it reads */
+        full = end_b >> 2;
         w0 = w1 = w2 = widx = fill = 0;
         p0 = p1 = p2 = p3 = 0;
         pend = false;
     }
+    /* dword idx of a block that reaches past the packet, branch-free: fetch it (or, behind the packet, the last dword
+     * that holds packet bytes: an address that is always good), keep what is packet data */
+    ALAC_DEV uint32_t tail1(uint32_t idx) const {
+        const uint32_t last = end_b ? (end_b - 1u) >> 2 : 0u;
+        const uint32_t v = base[umin(idx, last)];
+        const uint32_t lo = idx * 4u;
+        const uint32_t nb = end_b > lo ? umin(end_b - lo, 4u) : 0u;
+        return v & (nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u));
+    }
     ALAC_DEV void load4(uint32_t at) {
         /* one 16-byte load, 4-byte aligned. The dwords stay RAW (little-endian) in p0..p3: touching them here
          * would make the wave wait for the load on the spot; commit() swaps them four steps later. */
-        ALAC_LOAD4(base + at, p0, p1, p2, p3);
+        if (at + 4u <= full) {
+            ALAC_LOAD4(base + at, p0, p1, p2, p3);
+        } else { /* the last blocks of the packet, and everything behind it */
+            p0 = tail1(at);
+            p1 = tail1(at + 1u);
+            p2 = tail1(at + 2u);
+            p3 = tail1(at + 3u);
+        }
     }
     ALAC_DEV void commit(W& wv) {
         wv.ring_write4(fill & 31u, __builtin_bswap32(p0), __builtin_bswap32(p1), __builtin_bswap32(p2),
@@ -178,10 +205,8 @@ struct RingRd {
         pend = false;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            if (fill < limit) {
-                load4(fill);
-                commit(wv);
-            }
+            load4(fill);
+            commit(wv);
         }
         reseek(wv, pos);
     }
@@ -189,8 +214,9 @@ struct RingRd {
         widx = (pos + bias) >> 5;
         /* a slow-path step (escape code + zero-run code) can eat more than one dword, more than tick() puts
          * back: top the ring up on the spot whenever it runs low. Plain steps take <= 32 bits (prefix + 1 + k,
-         * k <= 23), which the 4 dwords per 4 steps of tick() cover. */
-        while (fill < widx + 12u && fill < limit) {
+         * k <= 23), which the 4 dwords per 4 steps of tick() cover. Positions are < 2^29 bits here (a live lane
+         * stays below max_pos + 66), so the loop ends. */
+        while (fill < widx + 12u) {
             if (!pend) load4(fill);
             commit(wv);
         }
@@ -215,7 +241,7 @@ struct RingRd {
     /* every 4th step, wave-uniform */
     ALAC_DEV void tick(W& wv) {
         if (pend) commit(wv);
-        if (fill + 4u <= widx + 32u && fill < limit) {
+        if (fill + 4u <= widx + 32u) {
             load4(fill);
             pend = true;
         }
@@ -234,8 +260,8 @@ struct RegLane {
  * zero run. Redoes the sample from its start with the stateless reader; returns the residual. Works on local
  * copies and writes the lane state back once (stores into the state from several exits make the compiler keep
  * it in scratch memory). */
-template <class W>
-ALAC_DEV int32_t golomb_slow(const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
+template <class W, class B>
+ALAC_DEV int32_t golomb_slow(const B& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
                              uint32_t chan_bits, uint32_t i, uint32_t ns) {
     uint32_t pos = s.pos, mean = s.mean, zmode = s.zmode, zrem = s.zrem;
     int32_t err = 0, del = 0;
@@ -314,8 +340,8 @@ ALAC_DEV int32_t golomb_slow(const Bits& bits, RegLane<W>& s, uint32_t size, uin
  * ns_live: the lane's sample count, 0 once the lane has failed (i >= ns_live: a dead step, nothing moves).
  * on_mask: ~0 when i < ns_live, carried from the previous step (updated here for step i+1).
  */
-template <class W>
-ALAC_DEV int32_t gol_step(W& wv, const Bits& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
+template <class W, class B>
+ALAC_DEV int32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
                           uint32_t chan_bits, uint32_t i, uint32_t ns, uint32_t& ns_live, uint32_t& on_mask) {
     const uint32_t k = umin(31u - clz32((s.mean >> 9) + 3u), kb); /* 1..23 */
     const uint32_t w = s.rd.window(s.pos);
@@ -451,8 +477,8 @@ enum { OUT_UTILE = 0,  /* U of a pair: hand-off tile */
        OUT_RAW = 3 };  /* int32 samples into this lane's row (split pipeline, alac_split.h) */
 
 /* Entropy scan of one channel for decode_wave<..., SCAN>: the lean Golomb loop with nothing behind it. */
-template <class W>
-ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const Bits& bits, const uint8_t* pkt, uint32_t size, bool go,
+template <class W, class B>
+ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_t* pkt, uint32_t size, bool go,
                            uint32_t& pos, uint32_t ns, uint32_t pb_local, uint32_t chan_bits, int32_t& err) {
     RegLane<W> s;
     s.rd.init(pkt, size);

@@ -40,9 +40,9 @@ constexpr uint32_t TASK_NONE = 0xffffu;
  * a task with the same key (live = false: no task) */
 template <class W, int ROLE>
 ALAC_DEV void decode_channel_task(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
-                                  const ChanDesc& d, int32_t* row) {
+                                  uint32_t avail, const ChanDesc& d, int32_t* row) {
     constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
-    const Bits bits{pkt, size};
+    const Bits bits{pkt, size, avail};
     const uint32_t na = key & 31u;
     const bool narrow = (key & 32u) == 0;
     RegLane<W> s;
@@ -73,9 +73,9 @@ ALAC_DEV void decode_channel_task(W& wv, const DevCfg& cfg, uint32_t key, bool l
 
 /* PCM of frame i of one split packet, written at `frame` (num_channels * bps bytes; the kernel stages 256 frames
  * in LDS and copies them out as whole lines). rows: the packet's sample rows, row r at rows + r*row_stride. */
-ALAC_DEV void interleave_frame(const DevCfg& cfg, const uint8_t* pkt, uint32_t size, const PktDesc& pd,
+ALAC_DEV void interleave_frame(const DevCfg& cfg, const uint8_t* pkt, uint32_t size, uint32_t avail, const PktDesc& pd,
                                const ChanDesc* cd, const int32_t* rows, size_t row_stride, uint32_t i, uint8_t* frame) {
-    const Bits bits{pkt, size};
+    const Bits bits{pkt, size, avail};
     const uint32_t num_chan = cfg.num_channels, bps = cfg.bps, depth = cfg.bit_depth;
     for (uint32_t slot = 0; slot < pd.nslots; ++slot) {
         const ChanDesc d = cd[slot];

@@ -69,17 +69,50 @@ ALAC_DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 ALAC_DEV uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 /* ---- stateless bit access (headers, escape elements, shift bytes, rare codes) ---------------------------
- * 64-bit big-endian window whose MSB is stream bit `pos` (>= 57 valid bits). The byte offset is clamped to
- * size+8 so a corrupt position never leaves the packet's zero pad (ALACGPU_PACKET_PAD); every consumer of
- * such a position raises a status before the data could matter. */
-struct Bits {
+ * 64-bit big-endian window whose MSB is stream bit `pos` (>= 57 valid bits). Packets lie DENSELY in the blob (an
+ * mdat as it is in the file, internal/mp4/mp4.go:382-420): what follows a packet is its neighbour, not padding. The
+ * reference sees every packet followed by 4 zero bytes (bitbuffer.go:33) and panics beyond them, so bytes from `size`
+ * on read as ZERO here, and nothing at or beyond `avail` (the bytes of the blob from the packet's start) is touched.
+ * The byte offset is clamped to size+8: every consumer of a position that far out raises a status before the data
+ * could matter. */
+template <bool SMALL>
+struct BitsT {
     const uint8_t* p;
     uint32_t size;
+    uint32_t avail; /* readable bytes from p (>= size), capped at 2^32-1; the readers never need it: they stay inside size */
 
     ALAC_DEV uint64_t window(uint32_t pos) const {
-        uint32_t b = umin(pos >> 3, size + 8u);
+        const uint32_t b = umin(pos >> 3, size + 8u);
         uint64_t raw;
-        __builtin_memcpy(&raw, p + b, 8);
+        if (!SMALL || size >= 8u) { /* SMALL = false: the caller knows size >= 8 (regular packets: >= 12) */
+            /* no branch on where the window lies: the load is pulled back so that it ends with the packet's last byte
+             * and the bytes it was pulled back over are shifted out again — zeros come in for everything behind the
+             * packet (memory order: the first byte is the low one) */
+            const uint32_t bb = umin(b, size - 8u);
+            const uint32_t d = b - bb; /* 0..16 */
+            __builtin_memcpy(&raw, p + bb, 8);
+            raw = d >= 8u ? 0ull : raw >> (8u * d);
+        } else if (size != 0u) {
+            /* a packet of fewer than 8 bytes lies in at most three aligned dwords, each of which holds a packet byte
+             * (or is fetched as the last one that does): assemble them, drop the bytes in front, keep `size` bytes */
+            const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(p - mis);
+            const uint32_t last = (mis + size - 1u) >> 2;
+            const uint64_t lo = (uint64_t)q[0] | ((uint64_t)q[umin(1u, last)] << 32);
+            const uint64_t hi = q[umin(2u, last)];
+            uint64_t v = mis ? (lo >> (8u * mis)) | (hi << (64u - 8u * mis)) : lo;
+            v &= (1ull << (8u * size)) - 1ull;
+            raw = b >= 8u ? 0ull : v >> (8u * b);
+        } else {
+            raw = 0;
+        }
+        return __builtin_bswap64(raw) << (pos & 7u);
+    }
+    /* the same without the end handling, for windows the caller knows to lie wholly inside the packet (the shift
+     * values of a regular packet: classify_regular keeps 8 bytes of entropy stream behind them) */
+    ALAC_DEV uint64_t window_raw(uint32_t pos) const {
+        uint64_t raw;
+        __builtin_memcpy(&raw, p + (pos >> 3), 8);
         return __builtin_bswap64(raw) << (pos & 7u);
     }
     /* n bits (0..32) at pos: BitBuffer.Read / ReadSmall / ReadOne all reduce to this (bitbuffer.go:55-96) */
@@ -92,6 +125,7 @@ struct Bits {
     ALAC_DEV bool read_small_panics(uint32_t pos) const { return (pos >> 3) > size + 2u; }
     ALAC_DEV bool past_end(uint32_t pos) const { return (pos >> 3) >= size; } /* bitbuffer.go:115 */
 };
+using Bits = BitsT<true>;
 
 /* Advance (bitbuffer.go:99-103): BitIdx is uint32 and wraps; positions far past the packet are clamped
  * (every later use of them errors the same way wherever they are). */
@@ -100,21 +134,33 @@ ALAC_DEV uint32_t advance(uint32_t pos, uint32_t nbits) {
     return np > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)np;
 }
 
-/* ---- the hot-loop bit reader: three big-endian dwords of the stream cached in registers ------------------
+/* ---- the whole-packet decoder's bit reader: three big-endian dwords of the stream cached in registers ------
  * w0,w1 hold stream dwords widx, widx+1; w2 (dword widx+2) is loaded one step ahead so its latency hides
  * behind ~3 samples of work. window() is one 64-bit funnel shift. A step consumes < 32 bits, so the
- * cache slides by at most one dword per call of slide(). Reads stay inside size + ALACGPU_PACKET_PAD. */
+ * cache slides by at most one dword per call of slide(). Dwords are fetched whole and aligned: one that holds at
+ * least one packet byte lies in the blob's pages; bytes from end_b on (the neighbour packet) are cleared, dwords
+ * wholly behind the packet are not fetched at all (dense blob, see Bits). */
 struct FastRd {
     const uint32_t* base; /* packet start rounded down to a dword */
     uint32_t bias;        /* stream bit 0 is bit `bias` of base[0] */
+    uint32_t end_b;       /* first byte, counted from base, that is not packet data */
     uint32_t w0, w1, w2, widx;
 
-    ALAC_DEV static uint32_t ld(const uint32_t* q) { return __builtin_bswap32(*q); }
+    ALAC_DEV uint32_t ld(uint32_t idx) const {
+        /* branch-free: fetch the dword (or, behind the packet, the last one that holds packet bytes), keep what is
+         * packet data. end_b >= 1 for a lane with a packet; a lane without one reads base[0] and keeps nothing. */
+        const uint32_t last = end_b ? (end_b - 1u) >> 2 : 0u;
+        const uint32_t v = base[umin(idx, last)];
+        const uint32_t lo = umin(idx, 0x3fffffffu) * 4u;
+        const uint32_t nb = end_b > lo ? umin(end_b - lo, 4u) : 0u; /* packet bytes in dword idx */
+        const uint32_t keep = nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u);
+        return __builtin_bswap32(v & keep);
+    }
     ALAC_DEV void seek(uint32_t pos) {
         widx = (pos + bias) >> 5;
-        w0 = ld(base + widx);
-        w1 = ld(base + widx + 1);
-        w2 = ld(base + widx + 2);
+        w0 = ld(widx);
+        w1 = ld(widx + 1);
+        w2 = ld(widx + 2);
     }
     ALAC_DEV uint32_t window(uint32_t pos) const {
         const uint32_t r = (pos + bias) & 31u;
@@ -125,7 +171,7 @@ struct FastRd {
             w0 = w1;
             w1 = w2;
             ++widx;
-            w2 = ld(base + widx + 2);
+            w2 = ld(widx + 2);
         }
     }
 };
@@ -170,8 +216,8 @@ ALAC_DEV uint32_t classify_orders(uint32_t nu, uint32_t nv) {
 
 /* First element's predictor orders without decoding anything (the sort key). Packets that start with
  * DSE/FIL/END, an escape element or garbage get class NA4: any class is correct for any packet. */
-ALAC_DEV uint32_t classify_packet(const uint8_t* pkt, uint32_t size) {
-    const Bits bits{pkt, size};
+ALAC_DEV uint32_t classify_packet(const uint8_t* pkt, uint32_t size, uint32_t avail) {
+    const Bits bits{pkt, size, avail};
     if (size < 8) return CLASS_NA4;
     const uint32_t tag = bits.get(0, 3);
     if (!(tag == 0 || tag == 1 || tag == 3)) return CLASS_NA4;
@@ -212,8 +258,8 @@ struct PktDesc {
 enum { ROUTE_NONE = 0, ROUTE_SPLIT = 1, ROUTE_LEGACY = 2 };
 
 /* Golomb-only pass over one channel (defined in alac_regular.h): advances pos to the end of the entropy stream */
-template <class W>
-ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const Bits& bits, const uint8_t* pkt, uint32_t size, bool go,
+template <class W, class B>
+ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_t* pkt, uint32_t size, bool go,
                            uint32_t& pos, uint32_t ns, uint32_t pb_local, uint32_t chan_bits, int32_t& err);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -231,13 +277,13 @@ ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const Bits& bits, const uin
  * Returns the status word; *frames_out = numSamples of the last element (decoder.go:206).
  * ------------------------------------------------------------------------------------------------------ */
 template <class W, int NA, bool WRAP, bool SCAN = false>
-ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t* pkt, uint32_t size, uint8_t* out,
-                             uint32_t* frames_out, ChanDesc* cd = nullptr, PktDesc* pd = nullptr) {
+ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t* pkt, uint32_t size, uint32_t avail,
+                             uint8_t* out, uint32_t* frames_out, ChanDesc* cd = nullptr, PktDesc* pd = nullptr) {
     /* SCAN: walk the packet exactly like a decode (same errors in the same order) but only find where every
      * channel's entropy stream starts and ends (scan_channel), describe the channels in cd[0..7] and the packet
      * in *pd; no prediction, no PCM. */
     bool legacy = false;
-    const Bits bits{pkt, size};
+    const Bits bits{pkt, size, avail};
     const uint32_t num_chan = cfg.num_channels;
     const uint32_t bps = cfg.bps;
     const uint32_t frame_stride = num_chan * bps;
@@ -250,6 +296,7 @@ ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t*
         const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(pkt) & 3u);
         rd.base = reinterpret_cast<const uint32_t*>(pkt - mis);
         rd.bias = mis * 8u;
+        rd.end_b = size ? mis + size : 0u;
     }
     rd.w0 = rd.w1 = rd.w2 = rd.widx = 0;
 
@@ -467,7 +514,7 @@ ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t*
             int32_t dprev = 0; /* delta pre-pass state (mode != 0) */
             if (SCAN) {
                 int32_t e2 = 0;
-                scan_channel<W>(wv, cfg, bits, pkt, size, run && !escape && ns != 0, pos, ns, pb_local, chan_bits, e2);
+                scan_channel(wv, cfg, bits, pkt, size, run && !escape && ns != 0, pos, ns, pb_local, chan_bits, e2);
                 if (run && e2) {
                     err = e2;
                     err_chan = c;

@@ -22,11 +22,17 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #define ALAC_DEV __device__ __forceinline__
 #define ALAC_NOINLINE
@@ -79,6 +85,7 @@ __device__ __forceinline__ int32_t alac_msub24(int32_t acc, int32_t a, int32_t n
 #define ALAC_SUBSAT(a, b) __builtin_elementwise_sub_sat((uint32_t)(a), (uint32_t)(b))
 #define ALAC_MULU24(a, b) __umul24((unsigned)(a), (unsigned)(b))
 #define ALAC_PICK(dst, src) asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(src))
+#define ALAC_OWN_REG(x) asm volatile("" : "+v"(x))
 typedef uint32_t alac_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 #define ALAC_LOAD4(q, a, b, c, d)                                                       \
     do {                                                                                \
@@ -247,23 +254,53 @@ struct GpuWave {
     ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * ppw; }
 };
 
-/* Sort-key histogram of one 256-thread block in LDS; only the keys the block saw go to the global counters
+/* readable bytes of the blob from a packet's start, as Bits wants them */
+__device__ __forceinline__ uint32_t avail_of(uint64_t blob_bytes, uint64_t off) {
+    const uint64_t left = blob_bytes - off;
+    return left > 0xffffffffull ? 0xffffffffu : (uint32_t)left;
+}
+
+/* Packet descriptors are checked here, once: a packet must lie inside the blob (the caller's offsets and sizes are
+ * untrusted device data). One that does not gets ALACGPU_ERR_RANGE, no sort key, and is never looked at again; the
+ * sizes every later kernel uses are the checked copies in sizes_ws. d_sizes may be null: packet i is then
+ * blob[offsets[i], offsets[i+1]) (the host entry's offsets[n+1]).
+ * Sort-key histogram of one 256-thread block in LDS; only the keys the block saw go to the global counters
  * (a batch has a dozen distinct keys: per-packet global atomics on them serialise). */
 __global__ void __launch_bounds__(256)
-alac_classify(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
-              const uint32_t* __restrict__ sizes, uint32_t n, uint16_t* __restrict__ keys, Plan* plan) {
+alac_classify(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
+              const uint32_t* __restrict__ sizes, uint32_t n, uint16_t* __restrict__ keys, uint32_t* __restrict__ sizes_ws,
+              uint32_t* __restrict__ frames_out, int32_t* __restrict__ status, Plan* plan) {
     __shared__ uint32_t hist[kKeys];
     for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x) hist[k] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        const uint8_t* p = blob + offsets[i];
-        uint32_t key = alac::classify_regular(cfg, p, sizes[i]);
-        /* not regular: scan first (with a usable KB). More than two channels: split pipeline. One or two: escape
-         * elements are unpacked by alac_interleave, anything else is handed to the whole-packet decoder. */
-        if (key == alac::KEY_IRREGULAR) key = cfg.kb != 0 ? kKeyScan : kKeyLegacy;
-        keys[i] = (uint16_t)key;
-        atomicAdd(&hist[key], 1u);
+        const uint64_t off = offsets[i];
+        uint64_t sz = sizes ? (uint64_t)sizes[i] : offsets[i + 1] - off;
+        const bool ok = off <= blob_bytes && sz <= blob_bytes - off && sz <= 0x0fffffffull &&
+                        (sizes || offsets[i + 1] >= off);
+        if (!ok) {
+            keys[i] = (uint16_t)alac::TASK_NONE;
+            sizes_ws[i] = 0;
+            frames_out[i] = 0;
+            status[i] = ALACGPU_ERR_RANGE;
+        } else if (sz == 0) {
+            /* an empty packet: PastEnd before the first tag (decoder.go:143-145). Settled here so that the readers
+             * only ever see packets of at least one byte (their loads are anchored on the packet's last byte). */
+            keys[i] = (uint16_t)alac::TASK_NONE;
+            sizes_ws[i] = 0;
+            frames_out[i] = 0;
+            status[i] = ALACGPU_STATUS(alac::ST_OVERRUN, 0, 0);
+        } else {
+            sizes_ws[i] = (uint32_t)sz;
+            const uint8_t* p = blob + off;
+            uint32_t key = alac::classify_regular(cfg, p, (uint32_t)sz, avail_of(blob_bytes, off));
+            /* not regular: scan first (with a usable KB). More than two channels: split pipeline. One or two: escape
+             * elements are unpacked by alac_interleave, anything else is handed to the whole-packet decoder. */
+            if (key == alac::KEY_IRREGULAR) key = cfg.kb != 0 ? kKeyScan : kKeyLegacy;
+            keys[i] = (uint16_t)key;
+            atomicAdd(&hist[key], 1u);
+        }
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x)
@@ -353,7 +390,7 @@ alac_scatter(const uint16_t* __restrict__ keys, uint32_t n, Plan* plan, uint32_t
  * With a usable KB they are scanned (status, frame count, channel descriptors: split pipeline step 1, PCM comes
  * from the later kernels); with KB == 0 the whole-packet decoder takes them. */
 __global__ void __launch_bounds__(kWave)
-alac_scan(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+alac_scan(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
           const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
           uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
           int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g,
@@ -377,16 +414,19 @@ alac_scan(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __
     wv.lane = lane;
     wv.wcnt = wv.flushed = 0;
 
-    const uint8_t* p = blob + (live ? offsets[pkt] : offsets[0]);
+    /* lanes without a packet read nothing (size 0) */
+    const uint64_t off = live ? offsets[pkt] : 0ull;
+    const uint8_t* p = blob + off;
     const uint32_t size = live ? sizes[pkt] : 0u;
+    const uint32_t avail = avail_of(blob_bytes, off);
     uint8_t* o = out + (size_t)pkt * out_stride;
     uint32_t frames = 0;
     int32_t st;
     const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
     if (ukey == kKeyScan)
-        st = alac::decode_wave<GpuWave, 16, true, true>(wv, cfg, live, p, size, o, &frames, cd + (size_t)pkt * 8u, pd + pkt);
+        st = alac::decode_wave<GpuWave, 16, true, true>(wv, cfg, live, p, size, avail, o, &frames, cd + (size_t)pkt * 8u, pd + pkt);
     else
-        st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, o, &frames);
+        st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, avail, o, &frames);
     if (live) {
         frames_out[pkt] = frames;
         status[pkt] = st;
@@ -397,7 +437,7 @@ alac_scan(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __
  * wave 1 = role B (predictor + PCM), lane = packet in both. Two waves per SIMD (four workgroups per CU) is what
  * the pair is built for: the register budget is capped there. */
 __global__ void __launch_bounds__(2 * kWave, 2)
-alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
             const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
             uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
             int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, uint32_t ppw) {
@@ -423,8 +463,11 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     wv.lane = lane;
     wv.wcnt = wv.flushed = 0;
 
-    const uint8_t* p = blob + (live ? offsets[pkt] : offsets[0]);
+    /* lanes without a packet read nothing (size 0) */
+    const uint64_t off = live ? offsets[pkt] : 0ull;
+    const uint8_t* p = blob + off;
     const uint32_t size = live ? sizes[pkt] : 0u;
+    const uint32_t avail = avail_of(blob_bytes, off);
     uint8_t* o = out + (size_t)pkt * out_stride;
     uint32_t frames = 0;
     /* the key is wave-uniform (one key per workgroup): scalar branches pick the variant */
@@ -438,7 +481,7 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
         if (na_max > 8u && na_max != 31u) __builtin_amdgcn_s_setprio(ALAC_PRIO_B_LONG);
         else if (na_max >= 6u && na_max != 31u) __builtin_amdgcn_s_setprio(ALAC_PRIO_B_MID);
         else __builtin_amdgcn_s_setprio(ALAC_PRIO_B_SHORT);
-        (void)alac::decode_regular_duo<GpuWave, alac::ROLE_B>(wv, cfg, ukey, live, p, size, o, &frames);
+        (void)alac::decode_regular_duo<GpuWave, alac::ROLE_B>(wv, cfg, ukey, live, p, size, avail, o, &frames);
 #ifdef ALAC_DUO_PROF
         if (lane == 0)
             for (int k = 0; k < 4; ++k) atomicAdd(&g_duo_prof[8 + k], wv.prof[k]);
@@ -453,7 +496,7 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
         if (alac::duo_emit_in_a(cpe ? (ukey & 31u) : (ukey >> 5), cpe)) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(ALAC_PRIO_A);
     }
-    const int32_t st = alac::decode_regular_duo<GpuWave, alac::ROLE_A>(wv, cfg, ukey, live, p, size, o, &frames);
+    const int32_t st = alac::decode_regular_duo<GpuWave, alac::ROLE_A>(wv, cfg, ukey, live, p, size, avail, o, &frames);
 #ifdef ALAC_DUO_PROF
     if (lane == 0)
         for (int k = 0; k < 4; ++k) atomicAdd(&g_duo_prof[k], wv.prof[k]);
@@ -492,7 +535,7 @@ alac_task_classify(alac::DevCfg cfg, const alac::ChanDesc* __restrict__ cd, cons
 
 /* a wave pair per 64 channel tasks with the same key: int32 samples of the channel into its row */
 __global__ void __launch_bounds__(2 * kWave, 2)
-alac_chan_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+alac_chan_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
                  const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
                  const alac::ChanDesc* __restrict__ cd, int32_t* __restrict__ rows, uint64_t row_stride, uint32_t ppw) {
     const uint32_t b = blockIdx.x;
@@ -516,8 +559,11 @@ alac_chan_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint6
     wv.lane = lane;
     wv.wcnt = wv.flushed = 0;
 
-    const uint8_t* p = blob + (live ? offsets[pkt] : offsets[0]);
+    /* lanes without a packet read nothing (size 0) */
+    const uint64_t off = live ? offsets[pkt] : 0ull;
+    const uint8_t* p = blob + off;
     const uint32_t size = live ? sizes[pkt] : 0u;
+    const uint32_t avail = avail_of(blob_bytes, off);
     alac::ChanDesc d = cd[t];
     if (!live) d.hdr_pos = d.ent_pos = d.ns = 0;
     int32_t* row = rows + ((size_t)pkt * cfg.num_channels + slot) * row_stride;
@@ -527,18 +573,18 @@ alac_chan_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint6
         if (na > 8u && na != 31u) __builtin_amdgcn_s_setprio(ALAC_PRIO_B_LONG);
         else if (na >= 6u && na != 31u) __builtin_amdgcn_s_setprio(ALAC_PRIO_B_MID);
         else __builtin_amdgcn_s_setprio(ALAC_PRIO_B_SHORT);
-        alac::decode_channel_task<GpuWave, alac::ROLE_B>(wv, cfg, ukey, live, p, size, d, row);
+        alac::decode_channel_task<GpuWave, alac::ROLE_B>(wv, cfg, ukey, live, p, size, avail, d, row);
         return;
     }
     __builtin_amdgcn_s_setprio(ALAC_PRIO_A);
-    alac::decode_channel_task<GpuWave, alac::ROLE_A>(wv, cfg, ukey, live, p, size, d, row);
+    alac::decode_channel_task<GpuWave, alac::ROLE_A>(wv, cfg, ukey, live, p, size, avail, d, row);
 }
 
 /* one thread per (packet, frame) of the split packets: PCM in frame order. Blocks stride over the scanned
  * packets (the tail of the permutation that belongs to kKeyScan) x 256-frame slices. A slice is assembled in LDS
  * (a frame is 1..32 bytes at a byte offset of its own) and copied out as 16-byte pieces, whole lines at a time. */
 __global__ void __launch_bounds__(256)
-alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
                 const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
                 const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd, const int32_t* __restrict__ rows,
                 uint64_t row_stride, uint8_t* __restrict__ out, uint64_t out_stride, uint32_t blocks_per_pkt) {
@@ -556,7 +602,7 @@ alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64
         const uint32_t nf = min(q.frames - f0, (uint32_t)blockDim.x);
         const uint32_t f = f0 + threadIdx.x;
         if (threadIdx.x < nf)
-            alac::interleave_frame(cfg, blob + offsets[pkt], sizes[pkt], q, cd + (size_t)pkt * 8u,
+            alac::interleave_frame(cfg, blob + offsets[pkt], sizes[pkt], avail_of(blob_bytes, offsets[pkt]), q, cd + (size_t)pkt * 8u,
                                    rows + (size_t)pkt * cfg.num_channels * row_stride, (size_t)row_stride, f,
                                    s_slice + threadIdx.x * fb);
         __syncthreads();
@@ -575,7 +621,7 @@ alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64
 
 /* packets the scan routed to the whole-packet decoder (orders 17..30): same wave mapping as alac_decode */
 __global__ void __launch_bounds__(kWave)
-alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offsets,
+alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
             const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
             const alac::PktDesc* __restrict__ pd, uint8_t* __restrict__ out, uint64_t out_stride,
             uint32_t* __restrict__ frames_out, int32_t* __restrict__ status, int32_t* __restrict__ scratch_u,
@@ -601,10 +647,13 @@ alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, const uint64_t* 
     wv.my_out = nullptr;
     wv.lane = lane;
     wv.wcnt = wv.flushed = 0;
-    const uint8_t* p = blob + (live ? offsets[pkt] : offsets[0]);
+    /* lanes without a packet read nothing (size 0) */
+    const uint64_t off = live ? offsets[pkt] : 0ull;
+    const uint8_t* p = blob + off;
     const uint32_t size = live ? sizes[pkt] : 0u;
+    const uint32_t avail = avail_of(blob_bytes, off);
     uint32_t frames = 0;
-    const int32_t st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, out + (size_t)pkt * out_stride, &frames);
+    const int32_t st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, avail, out + (size_t)pkt * out_stride, &frames);
     if (live) {
         frames_out[pkt] = frames;
         status[pkt] = st;
@@ -681,18 +730,111 @@ struct HostBuf { /* pinned staging */
 
 } /* namespace */
 
+/* ---- host-side copy helpers of the host entry -------------------------------------------------------------- */
+namespace {
+
+/* A few worker threads for the staging copies of alacgpu_decode_batch (pageable caller memory <-> pinned staging):
+ * one thread moves ~10 GB/s, the PCIe link 50+. Created on first use, joined by alacgpu_destroy. */
+class CopyPool {
+public:
+    explicit CopyPool(unsigned threads) {
+        for (unsigned t = 0; t < threads; ++t) workers_.emplace_back([this] { run(); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    /* fn(k) for k in [0, tasks), on the workers and on the caller; returns when all are done */
+    void parallel_for(size_t tasks, const std::function<void(size_t)>& fn) {
+        if (tasks == 0) return;
+        if (workers_.empty() || tasks == 1) {
+            for (size_t k = 0; k < tasks; ++k) fn(k);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn;
+            tasks_ = tasks;
+            next_ = 0;
+            left_ = tasks;
+            ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void work() {
+        for (;;) {
+            size_t k;
+            const std::function<void(size_t)>* fn;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (!fn_ || next_ >= tasks_) return;
+                k = next_++;
+                fn = fn_;
+            }
+            (*fn)(k);
+            std::lock_guard<std::mutex> g(m_);
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    void run() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t tasks_ = 0, next_ = 0, left_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+constexpr int kSlots = 3; /* chunks in flight in the host entry: one uploading, one decoding, one downloading */
+
+/* one chunk of the host entry: device and pinned staging for its packets and its PCM */
+struct Slot {
+    DevBuf d_in;   /* [offsets (n+1) x u64 | packet bytes] */
+    DevBuf d_out;  /* [PCM n x d_stride | frames n x u32 | status n x i32] */
+    HostBuf h_in, h_out;
+    hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
+    size_t first = 0, n = 0;
+    bool busy = false;
+};
+
+} /* namespace */
+
 struct alacgpu_decoder {
     alacgpu_config cfg;
     alac::DevCfg dev_cfg;
     int device;
     size_t frame_bytes;
-    hipStream_t stream;
+    hipStream_t stream;                                       /* kernels */
+    hipStream_t s_in, s_out;                                  /* host entry: uploads, downloads */
     hipEvent_t ev_start[kTimingSlots], ev_stop[kTimingSlots]; /* ring of per-launch event pairs */
     uint64_t launches;                                       /* since the last timing reset */
-    DevBuf scratch_u, scratch_g, plan, cls, perm;            /* kernel workspace */
+    DevBuf scratch_u, scratch_g, plan, cls, perm, sizes_ws;  /* kernel workspace */
     DevBuf cd, pd, plan2, keys2, perm2, rows;                /* split pipeline (more than two channels) */
-    DevBuf d_blob, d_offsets, d_sizes, d_out, d_frames, d_status; /* host-entry staging */
-    HostBuf h_blob, h_meta;
+    Slot slots[kSlots];                                      /* host-entry staging */
+    CopyPool* pool;
+    size_t chunk_bytes;                                      /* host entry: target bytes (in + out) per chunk */
 };
 
 namespace {
@@ -700,11 +842,12 @@ namespace {
 /* upper bound on the waves of a batch: every key present may end in one partly filled wave */
 size_t max_waves(size_t n, uint32_t ppw) { return (n + ppw - 1) / ppw + std::min<size_t>(n, 18 * 18 + 8); }
 
-/* Packets per wave. A VALU instruction costs the SIMD the same 4 cycles whether 64 lanes or 8 are live, so waves
- * are kept full while there is at least one workgroup per CU (256); a smaller batch is spread over narrower waves to
- * use CUs that would otherwise idle — but no further: a packet is a serial chain whose speed is highest when its
- * wave pair has a CU to itself (4 096 stereo packets: 2.57 ms on 1 024 four-lane pairs, 2.19 ms on 256 sixteen-lane
- * pairs; 32 768 packets: 2.63 ms on 1 024 half-full pairs, 2.43 ms on 512 full ones). */
+/* Packets per wave. A VALU instruction costs the SIMD the same whether 64 lanes or 8 are live (profiles/microbench/
+ * valu_multi_mi355x.txt, "half" rows), so waves are kept full while there is at least one workgroup per CU (256); a
+ * smaller batch is spread over narrower waves to use CUs that would otherwise idle — but no further: a packet is a
+ * serial chain whose speed is highest when its wave pair has a CU to itself (4 096 stereo packets: 2.57 ms on 1 024
+ * four-lane pairs, 2.19 ms on 256 sixteen-lane pairs; 32 768 packets: 2.63 ms on 1 024 half-full pairs, 2.43 ms on 512
+ * full ones). */
 uint32_t pick_ppw(size_t n) {
     if (const char* e = getenv("ALACGPU_PPW")) {
         const int v = atoi(e);
@@ -725,6 +868,7 @@ int reserve_workspace(alacgpu_decoder* dec, size_t n, uint32_t ppw) {
     if ((rc = dec->plan.ensure(sizeof(Plan)))) return rc;
     if ((rc = dec->cls.ensure((n ? n : 1) * sizeof(uint16_t)))) return rc;
     if ((rc = dec->perm.ensure((n ? n : 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = dec->sizes_ws.ensure((n ? n : 1) * sizeof(uint32_t)))) return rc;
     const size_t ns = (n ? n : 1) * 8;
     if ((rc = dec->cd.ensure(ns * sizeof(alac::ChanDesc)))) return rc;
     if ((rc = dec->pd.ensure((n ? n : 1) * sizeof(alac::PktDesc)))) return rc;
@@ -738,8 +882,10 @@ int reserve_workspace(alacgpu_decoder* dec, size_t n, uint32_t ppw) {
     return ALACGPU_E_OK;
 }
 
-int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offsets, const uint32_t* d_sizes,
-           size_t n, uint8_t* d_out, size_t out_stride, uint32_t* d_frames, int32_t* d_status) {
+/* All kernels of one decode, on the handle's stream. d_sizes may be null (packet i = blob[offsets[i], offsets[i+1])).
+ * The event pair brackets everything the decode launches, the sort pre-pass included. */
+int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, const uint64_t* d_offsets,
+           const uint32_t* d_sizes, size_t n, uint8_t* d_out, size_t out_stride, uint32_t* d_frames, int32_t* d_status) {
     if (n == 0) return ALACGPU_E_OK;
     if (n > 0x7fffffffu) {
         set_err("batch too large");
@@ -751,24 +897,25 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
     alac::DevCfg c = dec->dev_cfg;
     c.aligned16 = (out_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(d_out) % 16) == 0) ? 1u : 0u;
     Plan* plan = (Plan*)dec->plan.p;
+    const uint32_t* sz = (const uint32_t*)dec->sizes_ws.p; /* the checked sizes (alac_classify) */
     const uint32_t nb = (uint32_t)((n + 255) / 256);
+    const uint32_t slot = (uint32_t)(dec->launches % kTimingSlots);
+    HIP_TRY(hipEventRecord(dec->ev_start[slot], dec->stream));
     HIP_TRY(hipMemsetAsync(plan, 0, sizeof(Plan), dec->stream));
-    hipLaunchKernelGGL(alac_classify, dim3(nb), dim3(256), 0, dec->stream, c, d_blob, d_offsets, d_sizes, (uint32_t)n,
-                       (uint16_t*)dec->cls.p, plan);
+    hipLaunchKernelGGL(alac_classify, dim3(nb), dim3(256), 0, dec->stream, c, d_blob, blob_bytes, d_offsets, d_sizes,
+                       (uint32_t)n, (uint16_t*)dec->cls.p, (uint32_t*)dec->sizes_ws.p, d_frames, d_status, plan);
     hipLaunchKernelGGL(alac_plan, dim3(1), dim3(kWave), 0, dec->stream, plan, ppw);
     hipLaunchKernelGGL(alac_scatter, dim3(nb), dim3(256), 0, dec->stream, (const uint16_t*)dec->cls.p, (uint32_t)n, plan,
                        (uint32_t*)dec->perm.p);
-    const uint32_t slot = (uint32_t)(dec->launches % kTimingSlots);
-    HIP_TRY(hipEventRecord(dec->ev_start[slot], dec->stream));
     /* irregular packets first (usually a handful of waves, or none), then the wave pairs of the regular ones */
-    hipLaunchKernelGGL(alac_scan, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, d_offsets,
-                       d_sizes, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride, d_frames,
+    hipLaunchKernelGGL(alac_scan, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, blob_bytes,
+                       d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride, d_frames,
                        d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw, (alac::ChanDesc*)dec->cd.p,
                        (alac::PktDesc*)dec->pd.p);
     if (dec->cfg.num_channels <= 2 && dec->cfg.kb != 0)
         hipLaunchKernelGGL(alac_decode, dim3((uint32_t)max_waves(n, ppw)), dim3(2 * kWave), 0, dec->stream, c, d_blob,
-                           d_offsets, d_sizes, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride,
-                           d_frames, d_status, (int32_t*)dec->scratch_u.p, ppw);
+                           blob_bytes, d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out,
+                           (uint64_t)out_stride, d_frames, d_status, (int32_t*)dec->scratch_u.p, ppw);
     HIP_TRY(hipGetLastError());
     if (dec->cfg.kb != 0) {
         /* irregular packets were only scanned by alac_scan (status, frames, channel descriptors) */
@@ -788,22 +935,31 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, const uint64_t* d_offset
             hipLaunchKernelGGL(alac_scatter, dim3(nb2), dim3(256), 0, dec->stream, (const uint16_t*)dec->keys2.p,
                                (uint32_t)n_slots, plan2, (uint32_t*)dec->perm2.p);
             hipLaunchKernelGGL(alac_chan_decode, dim3((uint32_t)max_waves(n_slots, ppw2)), dim3(2 * kWave), 0, dec->stream, c,
-                               d_blob, d_offsets, d_sizes, (const uint32_t*)dec->perm2.p, (const Plan*)plan2,
+                               d_blob, blob_bytes, d_offsets, sz, (const uint32_t*)dec->perm2.p, (const Plan*)plan2,
                                (const alac::ChanDesc*)dec->cd.p, (int32_t*)dec->rows.p, rs, ppw2);
         }
         /* PCM of the split packets (with one or two channels: of the escape-only packets) */
         const uint32_t ib = (uint32_t)std::min<uint64_t>((uint64_t)n * bpp, 8192);
-        hipLaunchKernelGGL(alac_interleave, dim3(ib), dim3(256), 0, dec->stream, c, d_blob, d_offsets, d_sizes,
+        hipLaunchKernelGGL(alac_interleave, dim3(ib), dim3(256), 0, dec->stream, c, d_blob, blob_bytes, d_offsets, sz,
                            (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::ChanDesc*)dec->cd.p,
                            (const alac::PktDesc*)dec->pd.p, (const int32_t*)dec->rows.p, rs, d_out, (uint64_t)out_stride, bpp);
-        hipLaunchKernelGGL(alac_legacy, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, d_offsets,
-                           d_sizes, (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::PktDesc*)dec->pd.p, d_out,
+        hipLaunchKernelGGL(alac_legacy, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, blob_bytes,
+                           d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::PktDesc*)dec->pd.p, d_out,
                            (uint64_t)out_stride, d_frames, d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(dec->ev_stop[slot], dec->stream));
     dec->launches++;
     return ALACGPU_E_OK;
+}
+
+bool is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError(); /* an ordinary (pageable) pointer: not an error */
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
 }
 
 } /* namespace */
@@ -841,14 +997,29 @@ int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out)
     d->dev_cfg = alac::DevCfg{cfg->frame_length, cfg->bit_depth, cfg->num_channels, cfg->pb, cfg->mb, cfg->kb,
                               (uint32_t)bps, 0u};
     d->launches = 0;
+    d->pool = nullptr;
+    d->chunk_bytes = (size_t)192 << 20;
+    if (const char* e = getenv("ALACGPU_CHUNK_MB")) {
+        const long v = atol(e);
+        if (v >= 1 && v <= 65536) d->chunk_bytes = (size_t)v << 20;
+    }
+    d->stream = d->s_in = d->s_out = nullptr;
+    for (uint32_t i = 0; i < kTimingSlots; i++) d->ev_start[i] = d->ev_stop[i] = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_in, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_out, hipStreamNonBlocking);
     for (uint32_t i = 0; i < kTimingSlots && e == hipSuccess; i++) {
         e = hipEventCreate(&d->ev_start[i]);
         if (e == hipSuccess) e = hipEventCreate(&d->ev_stop[i]);
     }
+    for (int k = 0; k < kSlots && e == hipSuccess; k++) {
+        e = hipEventCreateWithFlags(&d->slots[k].ev_in, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->slots[k].ev_k, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->slots[k].ev_out, hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         set_err("stream/event creation failed: %s", hipGetErrorString(e));
-        delete d;
+        alacgpu_destroy(d);
         return ALACGPU_E_HIP;
     }
     *out = d;
@@ -858,31 +1029,30 @@ int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out)
 void alacgpu_destroy(alacgpu_decoder* d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
-    (void)hipStreamSynchronize(d->stream);
-    d->scratch_u.release();
-    d->scratch_g.release();
-    d->plan.release();
-    d->cls.release();
-    d->perm.release();
-    d->cd.release();
-    d->pd.release();
-    d->plan2.release();
-    d->keys2.release();
-    d->perm2.release();
-    d->rows.release();
-    d->d_blob.release();
-    d->d_offsets.release();
-    d->d_sizes.release();
-    d->d_out.release();
-    d->d_frames.release();
-    d->d_status.release();
-    d->h_blob.release();
-    d->h_meta.release();
-    for (uint32_t i = 0; i < kTimingSlots; i++) {
-        (void)hipEventDestroy(d->ev_start[i]);
-        (void)hipEventDestroy(d->ev_stop[i]);
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
+    if (d->s_in) (void)hipStreamSynchronize(d->s_in);
+    if (d->s_out) (void)hipStreamSynchronize(d->s_out);
+    delete d->pool;
+    DevBuf* bufs[] = {&d->scratch_u, &d->scratch_g, &d->plan, &d->cls, &d->perm, &d->sizes_ws, &d->cd, &d->pd,
+                      &d->plan2, &d->keys2, &d->perm2, &d->rows};
+    for (DevBuf* b : bufs) b->release();
+    for (int k = 0; k < kSlots; k++) {
+        Slot& s = d->slots[k];
+        s.d_in.release();
+        s.d_out.release();
+        s.h_in.release();
+        s.h_out.release();
+        if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+        if (s.ev_k) (void)hipEventDestroy(s.ev_k);
+        if (s.ev_out) (void)hipEventDestroy(s.ev_out);
     }
-    (void)hipStreamDestroy(d->stream);
+    for (uint32_t i = 0; i < kTimingSlots; i++) {
+        if (d->ev_start[i]) (void)hipEventDestroy(d->ev_start[i]);
+        if (d->ev_stop[i]) (void)hipEventDestroy(d->ev_stop[i]);
+    }
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    if (d->s_in) (void)hipStreamDestroy(d->s_in);
+    if (d->s_out) (void)hipStreamDestroy(d->s_out);
     delete d;
 }
 
@@ -902,10 +1072,10 @@ int alacgpu_reserve(alacgpu_decoder* d, size_t n) {
     return reserve_workspace(d, n, pick_ppw(n));
 }
 
-int alacgpu_decode_batch_device(alacgpu_decoder* d, const uint8_t* d_blob, const uint64_t* d_offsets,
+int alacgpu_decode_batch_device(alacgpu_decoder* d, const uint8_t* d_blob, size_t blob_bytes, const uint64_t* d_offsets,
                                 const uint32_t* d_sizes, size_t n, uint8_t* d_out, size_t out_stride,
                                 uint32_t* d_frames, int32_t* d_status, int sync) {
-    if (!d || (n && (!d_blob || !d_offsets || !d_sizes || !d_out || !d_frames || !d_status))) {
+    if (!d || (n && (!d_offsets || !d_out || !d_frames || !d_status)) || (blob_bytes && !d_blob)) {
         set_err("null argument");
         return ALACGPU_E_ARG;
     }
@@ -914,15 +1084,22 @@ int alacgpu_decode_batch_device(alacgpu_decoder* d, const uint8_t* d_blob, const
         return ALACGPU_E_ARG;
     }
     HIP_TRY(hipSetDevice(d->device));
-    int rc = launch(d, d_blob, d_offsets, d_sizes, n, d_out, out_stride, d_frames, d_status);
+    int rc = launch(d, d_blob, (uint64_t)blob_bytes, d_offsets, d_sizes, n, d_out, out_stride, d_frames, d_status);
     if (rc) return rc;
     if (sync) HIP_TRY(hipStreamSynchronize(d->stream));
     return ALACGPU_E_OK;
 }
 
+/*
+ * DecodePackets from host memory: the batch is cut into chunks of whole packets; chunk c is uploaded on one stream
+ * while chunk c-1 decodes on the handle's stream and chunk c-2 comes back on a third. The packets go up exactly as
+ * they lie in the caller's blob (no re-pack: the kernels read dense blobs), together with their offsets, in ONE
+ * transfer; PCM, frame counts and status words come back in ONE. Pageable caller memory is staged through pinned
+ * buffers by a few copy threads; memory the caller pinned itself (hipHostMalloc / hipHostRegister) is used in place.
+ */
 int alacgpu_decode_batch(alacgpu_decoder* d, const uint8_t* blob, const uint64_t* offsets, size_t n, uint8_t* out,
                          size_t out_stride, uint32_t* frames_out, int32_t* status) {
-    if (!d || (n && (!blob || !offsets || !out || !frames_out || !status))) {
+    if (!d || (n && (!offsets || !out || !frames_out || !status))) {
         set_err("null argument");
         return ALACGPU_E_ARG;
     }
@@ -931,53 +1108,123 @@ int alacgpu_decode_batch(alacgpu_decoder* d, const uint8_t* blob, const uint64_t
         return ALACGPU_E_ARG;
     }
     if (n == 0) return ALACGPU_E_OK;
-    HIP_TRY(hipSetDevice(d->device));
-
-    /* re-pack into the device blob layout: 16-byte aligned packets, ALACGPU_PACKET_PAD zero bytes after each */
-    int rc = d->h_meta.ensure(n * (sizeof(uint64_t) + sizeof(uint32_t)));
-    if (rc) return rc;
-    uint64_t* h_off = (uint64_t*)d->h_meta.p;
-    uint32_t* h_sz = (uint32_t*)(h_off + n);
-    size_t total = 0;
     for (size_t i = 0; i < n; i++) {
         if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 0x0fffffffull) {
             set_err("bad offsets at packet %zu", i);
             return ALACGPU_E_ARG;
         }
-        const size_t len = (size_t)(offsets[i + 1] - offsets[i]);
-        h_off[i] = total;
-        h_sz[i] = (uint32_t)len;
-        total = (total + len + ALACGPU_PACKET_PAD + 15u) & ~(size_t)15u;
     }
-    total += 64;
-    if ((rc = d->h_blob.ensure(total))) return rc;
-    uint8_t* hb = (uint8_t*)d->h_blob.p;
-    for (size_t i = 0; i < n; i++) {
-        const size_t end = (i + 1 < n ? (size_t)h_off[i + 1] : total);
-        memcpy(hb + h_off[i], blob + offsets[i], h_sz[i]);
-        memset(hb + h_off[i] + h_sz[i], 0, end - (size_t)h_off[i] - h_sz[i]);
+    if (offsets[n] > offsets[0] && !blob) {
+        set_err("null argument");
+        return ALACGPU_E_ARG;
     }
-    /* keep the device output rows 16-byte aligned so the LDS-staged wide-store path is taken */
-    const size_t d_stride = (d->frame_bytes + 15u) & ~(size_t)15u;
-    if ((rc = d->d_blob.ensure(total))) return rc;
-    if ((rc = d->d_offsets.ensure(n * sizeof(uint64_t)))) return rc;
-    if ((rc = d->d_sizes.ensure(n * sizeof(uint32_t)))) return rc;
-    if ((rc = d->d_out.ensure(n * d_stride))) return rc;
-    if ((rc = d->d_frames.ensure(n * sizeof(uint32_t)))) return rc;
-    if ((rc = d->d_status.ensure(n * sizeof(int32_t)))) return rc;
+    HIP_TRY(hipSetDevice(d->device));
+    const size_t fb = d->frame_bytes;
+    const size_t d_stride = (fb + 15u) & ~(size_t)15u; /* 16-byte aligned device rows: the LDS-staged wide stores */
+    const bool out_pinned = is_pinned(out) && is_pinned(frames_out) && is_pinned(status);
+    const bool in_pinned = (offsets[n] == offsets[0]) || is_pinned(blob);
+    if (!d->pool && !(out_pinned && in_pinned)) {
+        unsigned t = std::thread::hardware_concurrency();
+        t = t > 16 ? 8 : (t > 2 ? t / 2 : 1);
+        if (const char* e = getenv("ALACGPU_COPY_THREADS")) t = (unsigned)std::max(1, atoi(e));
+        d->pool = new (std::nothrow) CopyPool(t - 1); /* the calling thread copies too */
+    }
 
-    HIP_TRY(hipMemcpyAsync(d->d_blob.p, hb, total, hipMemcpyHostToDevice, d->stream));
-    HIP_TRY(hipMemcpyAsync(d->d_offsets.p, h_off, n * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
-    HIP_TRY(hipMemcpyAsync(d->d_sizes.p, h_sz, n * sizeof(uint32_t), hipMemcpyHostToDevice, d->stream));
-    rc = launch(d, (const uint8_t*)d->d_blob.p, (const uint64_t*)d->d_offsets.p, (const uint32_t*)d->d_sizes.p, n,
-                (uint8_t*)d->d_out.p, d_stride, (uint32_t*)d->d_frames.p, (int32_t*)d->d_status.p);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(frames_out, d->d_frames.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipMemcpyAsync(status, d->d_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
-    HIP_TRY(hipMemcpy2DAsync(out, out_stride, d->d_out.p, d_stride, d->frame_bytes, n, hipMemcpyDeviceToHost,
-                             d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    return ALACGPU_E_OK;
+    auto finish = [&](Slot& s) -> int { /* chunk is back in pinned memory (or in place): hand it to the caller */
+        HIP_TRY(hipEventSynchronize(s.ev_out));
+        if (!out_pinned) {
+            const uint8_t* h = (const uint8_t*)s.h_out.p;
+            const uint8_t* hm = h + s.n * d_stride;
+            memcpy(frames_out + s.first, hm, s.n * sizeof(uint32_t));
+            memcpy(status + s.first, hm + s.n * sizeof(uint32_t), s.n * sizeof(int32_t));
+            const size_t pieces = std::min<size_t>(s.n, 64);
+            auto body = [&](size_t k) {
+                const size_t lo = s.n * k / pieces, hi = s.n * (k + 1) / pieces;
+                if (out_stride == d_stride) {
+                    memcpy(out + (s.first + lo) * out_stride, h + lo * d_stride, (hi - lo) * d_stride - (d_stride - fb));
+                } else {
+                    for (size_t i = lo; i < hi; i++) memcpy(out + (s.first + i) * out_stride, h + i * d_stride, fb);
+                }
+            };
+            if (d->pool) d->pool->parallel_for(pieces, body);
+            else for (size_t k = 0; k < pieces; k++) body(k);
+        }
+        s.busy = false;
+        return ALACGPU_E_OK;
+    };
+
+    size_t first = 0;
+    int turn = 0;
+    int rc = ALACGPU_E_OK;
+    while (first < n && rc == ALACGPU_E_OK) {
+        /* packets of this chunk: whole packets, about chunk_bytes of traffic (packet bytes in + PCM out) */
+        size_t cnt = 0;
+        uint64_t bytes = 0;
+        while (first + cnt < n && (cnt == 0 || bytes < d->chunk_bytes)) {
+            bytes += (offsets[first + cnt + 1] - offsets[first + cnt]) + fb;
+            cnt++;
+        }
+        Slot& s = d->slots[turn];
+        turn = (turn + 1) % kSlots;
+        if (s.busy && (rc = finish(s))) break;
+        s.first = first;
+        s.n = cnt;
+        const uint64_t b0 = offsets[first], b1 = offsets[first + cnt];
+        const size_t in_bytes = (size_t)(b1 - b0);
+        const size_t meta = (cnt + 1) * sizeof(uint64_t);
+        const size_t meta_pad = (meta + 255u) & ~(size_t)255u; /* packet bytes start 256-byte aligned on the device */
+        if ((rc = s.d_in.ensure(meta_pad + in_bytes + 16))) break;
+        if ((rc = s.d_out.ensure(cnt * d_stride + cnt * 8 + 16))) break;
+        if ((rc = s.h_in.ensure(in_pinned ? meta_pad : meta_pad + in_bytes))) break;
+        if (!out_pinned && (rc = s.h_out.ensure(cnt * d_stride + cnt * 8))) break;
+        /* upload: offsets rebased to the chunk's first byte, then the bytes */
+        uint64_t* h_off = (uint64_t*)s.h_in.p;
+        for (size_t i = 0; i <= cnt; i++) h_off[i] = offsets[first + i] - b0;
+        uint8_t* d_in = (uint8_t*)s.d_in.p;
+        if (in_pinned) {
+            HIP_TRY(hipMemcpyAsync(d_in, h_off, meta, hipMemcpyHostToDevice, d->s_in));
+            if (in_bytes) HIP_TRY(hipMemcpyAsync(d_in + meta_pad, blob + b0, in_bytes, hipMemcpyHostToDevice, d->s_in));
+        } else {
+            uint8_t* hb = (uint8_t*)s.h_in.p + meta_pad;
+            const size_t pieces = std::max<size_t>(1, std::min<size_t>(64, in_bytes >> 20));
+            auto body = [&](size_t k) {
+                const size_t lo = in_bytes * k / pieces, hi = in_bytes * (k + 1) / pieces;
+                memcpy(hb + lo, blob + b0 + lo, hi - lo);
+            };
+            if (d->pool) d->pool->parallel_for(pieces, body);
+            else for (size_t k = 0; k < pieces; k++) body(k);
+            HIP_TRY(hipMemcpyAsync(d_in, s.h_in.p, meta_pad + in_bytes, hipMemcpyHostToDevice, d->s_in));
+        }
+        HIP_TRY(hipEventRecord(s.ev_in, d->s_in));
+        /* decode */
+        HIP_TRY(hipStreamWaitEvent(d->stream, s.ev_in, 0));
+        uint8_t* d_pcm = (uint8_t*)s.d_out.p;
+        uint32_t* d_fr = (uint32_t*)(d_pcm + cnt * d_stride);
+        int32_t* d_st = (int32_t*)(d_fr + cnt);
+        if ((rc = launch(d, d_in + meta_pad, in_bytes, (const uint64_t*)d_in, nullptr, cnt, d_pcm, d_stride, d_fr, d_st))) break;
+        HIP_TRY(hipEventRecord(s.ev_k, d->stream));
+        /* download */
+        HIP_TRY(hipStreamWaitEvent(d->s_out, s.ev_k, 0));
+        if (out_pinned) {
+            HIP_TRY(hipMemcpy2DAsync(out + first * out_stride, out_stride, d_pcm, d_stride, fb, cnt, hipMemcpyDeviceToHost, d->s_out));
+            HIP_TRY(hipMemcpyAsync(frames_out + first, d_fr, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, d->s_out));
+            HIP_TRY(hipMemcpyAsync(status + first, d_st, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, d->s_out));
+        } else {
+            HIP_TRY(hipMemcpyAsync(s.h_out.p, d_pcm, cnt * d_stride + cnt * 8, hipMemcpyDeviceToHost, d->s_out));
+        }
+        HIP_TRY(hipEventRecord(s.ev_out, d->s_out));
+        s.busy = true;
+        first += cnt;
+    }
+    /* drain, oldest first */
+    for (int k = 0; k < kSlots; k++) {
+        Slot& s = d->slots[(turn + k) % kSlots];
+        if (!s.busy) continue;
+        const int r2 = finish(s);
+        if (rc == ALACGPU_E_OK) rc = r2;
+        s.busy = false;
+    }
+    return rc;
 }
 
 int alacgpu_decode_packet(alacgpu_decoder* d, const uint8_t* packet, size_t packet_len, uint8_t* out, size_t out_cap,
@@ -995,6 +1242,7 @@ int alacgpu_decode_packet(alacgpu_decoder* d, const uint8_t* packet, size_t pack
     const uint8_t dummy = 0;
     uint32_t frames = 0;
     int32_t st = 0;
+    /* a batch of one through the same entry: one upload (offsets + bytes), the kernels, one download */
     int rc = alacgpu_decode_batch(d, packet_len ? packet : &dummy, offs, 1, out, d->frame_bytes, &frames, &st);
     if (rc) return rc;
     if (status_out) *status_out = st;
@@ -1059,6 +1307,6 @@ int alacgpu_debug_prof(unsigned long long* out16) {
 }
 #endif
 
-const char* alacgpu_version(void) { return "alacgpu 0.2.0 gfx950"; }
+const char* alacgpu_version(void) { return "alacgpu 0.3.0 gfx950"; }
 
 } /* extern "C" */

@@ -54,10 +54,12 @@ def lane_sim(oracle):
                                "-o", so, srcs[0]])
     L = ctypes.CDLL(so)
     vp = ctypes.c_void_p
-    L.lane_sim_decode_batch.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp, vp, ctypes.c_int,
-                                        ctypes.c_int, vp]
+    L.lane_sim_decode_batch.argtypes = [vp, vp, ctypes.c_size_t, vp, vp, ctypes.c_size_t, vp, ctypes.c_size_t, vp, vp,
+                                        ctypes.c_int, ctypes.c_int, vp, ctypes.c_int]
 
-    def run(cfg, blob, offsets, sizes, variant=-1, stride_pad=0, want_classes=False):
+    def run(cfg, blob, offsets, sizes, variant=-1, stride_pad=0, want_classes=False, blob_bytes=None, guard=False):
+        """blob_bytes: the readable bytes of the blob (default: all of it); guard: run on a copy that ends at an
+        inaccessible page, so that any read past the blob is fatal."""
         n = len(offsets)
         stride = (oracle.frame_bytes(cfg) + 15) // 16 * 16 + stride_pad
         out = np.zeros((n, stride), np.uint8)
@@ -66,9 +68,10 @@ def lane_sim(oracle):
         st = np.zeros(n, np.int32)
         offsets = np.ascontiguousarray(offsets, np.uint64)
         sizes = np.ascontiguousarray(sizes, np.uint32)
-        L.lane_sim_decode_batch(ctypes.byref(cfg), blob.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, n,
-                                out.ctypes.data, stride, fr.ctypes.data, st.ctypes.data, 1, variant,
-                                classes.ctypes.data)
+        rc = L.lane_sim_decode_batch(ctypes.byref(cfg), blob.ctypes.data, len(blob) if blob_bytes is None else blob_bytes,
+                                     offsets.ctypes.data, sizes.ctypes.data, n, out.ctypes.data, stride, fr.ctypes.data,
+                                     st.ctypes.data, 1, variant, classes.ctypes.data, 1 if guard else 0)
+        assert rc == 0
         if want_classes:
             return out, fr, st, classes
         return out, fr, st
@@ -77,7 +80,8 @@ def lane_sim(oracle):
 
 
 def pack_packets(packets, pad=64):
-    """List of packet bytes -> (blob, offsets[n], sizes[n]) in the device blob layout."""
+    """List of packet bytes -> (blob, offsets[n], sizes[n]), every packet followed by `pad` zero bytes and aligned to
+    16 (the round-1 device layout; the decoder needs neither any more, see pack_dense)."""
     offs, sizes, buf = [], [], bytearray()
     for q in packets:
         offs.append(len(buf))
@@ -88,6 +92,18 @@ def pack_packets(packets, pad=64):
             buf.append(0)
     buf += bytes(64)
     return (np.frombuffer(bytes(buf), np.uint8).copy(), np.array(offs, np.uint64), np.array(sizes, np.uint32))
+
+
+def pack_dense(packets, lead=0):
+    """Packets back to back as in an mdat (internal/mp4/mp4.go:382-420): no padding, no alignment, the blob ends with
+    the last packet's last byte. lead: bytes of 0xFF in front (shifts every packet's alignment)."""
+    offs, sizes, buf = [], [], bytearray(b"\xff" * lead)
+    for q in packets:
+        offs.append(len(buf))
+        sizes.append(len(q))
+        buf += q
+    return (np.frombuffer(bytes(buf) if buf else b"\0", np.uint8).copy()[:len(buf)], np.array(offs, np.uint64),
+            np.array(sizes, np.uint32))
 
 
 def mutate_packets(batch, rng, n_out):
@@ -138,6 +154,7 @@ def helpers():
         pass
 
     H.pack_packets = staticmethod(pack_packets)
+    H.pack_dense = staticmethod(pack_dense)
     H.mutate_packets = staticmethod(mutate_packets)
     H.assert_same_decode = staticmethod(assert_same_decode)
     return H

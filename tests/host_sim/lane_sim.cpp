@@ -6,6 +6,9 @@
  * (-m "not gpu"), where no GPU exists. It lives under tests/, is never linked into libalacgpu.so and is not
  * a decode path of the product.
  */
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -68,10 +71,27 @@ struct HostWave {
  *                 for > 2 channels, whole-packet decoder otherwise);
  *          -2   = split pipeline for every non-regular packet, whatever the channel count.
  * classes_out (may be null) gets the sort key / route. */
-extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* blob, const uint64_t* offsets,
-                                     const uint32_t* sizes, size_t n, uint8_t* out, size_t out_stride,
-                                     uint32_t* frames_out, int32_t* status, int poison, int variant,
-                                     uint32_t* classes_out) {
+extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* blob_in, size_t blob_bytes,
+                                     const uint64_t* offsets, const uint32_t* sizes, size_t n, uint8_t* out,
+                                     size_t out_stride, uint32_t* frames_out, int32_t* status, int poison, int variant,
+                                     uint32_t* classes_out, int guard) {
+    /* guard: the blob is copied so that the aligned dword holding its last byte ends at a page boundary and the next
+     * page is inaccessible: a reader that looks further than the contract of Bits / RingRd allows dies here */
+    const uint8_t* blob = blob_in;
+    uint8_t* region = nullptr;
+    size_t region_len = 0;
+    if (guard) {
+        const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+        const size_t span = (blob_bytes + 3u) & ~(size_t)3u;
+        region_len = ((span + page - 1) / page + 1) * page;
+        region = (uint8_t*)mmap(nullptr, region_len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (region == MAP_FAILED) return -1;
+        uint8_t* b = region + (region_len - page) - span;
+        memset(region, 0xee, region_len - page);
+        memcpy(b, blob_in, blob_bytes);
+        mprotect(region + region_len - page, page, PROT_NONE);
+        blob = b;
+    }
     alac::DevCfg dc{};
     dc.frame_length = cfg->frame_length;
     dc.bit_depth = cfg->bit_depth;
@@ -90,14 +110,16 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
             memset(out + i * out_stride, 0xa5, out_stride);
         }
         const uint8_t* p = blob + offsets[i];
+        const uint64_t left = (uint64_t)blob_bytes - offsets[i];
+        const uint32_t avail = left > 0xffffffffull ? 0xffffffffu : (uint32_t)left;
         uint8_t* o = out + i * out_stride;
         frames_out[i] = 0;
         if (variant < 0) {
             /* like the GPU pre-pass: regular packets take the lean decoder */
-            const uint32_t key = alac::classify_regular(dc, p, sizes[i]);
+            const uint32_t key = alac::classify_regular(dc, p, sizes[i], avail);
             if (key != alac::KEY_IRREGULAR) {
                 if (classes_out) classes_out[i] = key;
-                status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH>(wv, dc, key, true, p, sizes[i], o,
+                status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH>(wv, dc, key, true, p, sizes[i], avail, o,
                                                                                 &frames_out[i]);
                 continue;
             }
@@ -107,7 +129,7 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
             alac::ChanDesc cd[8];
             memset(cd, 0, sizeof(cd));
             alac::PktDesc pd{};
-            status[i] = alac::decode_wave<HostWave, 16, true, true>(wv, dc, true, p, sizes[i], o, &frames_out[i], cd, &pd);
+            status[i] = alac::decode_wave<HostWave, 16, true, true>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i], cd, &pd);
             if (classes_out) classes_out[i] = 2048u + pd.route;
             if (status[i] != 0) continue;
             if (pd.route == alac::ROUTE_SPLIT) {
@@ -115,11 +137,11 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
                 std::vector<int32_t> rows(rs * 8, 0x5a5a5a5a);
                 for (uint32_t sl = 0; sl < pd.nslots; ++sl) {
                     if (!(cd[sl].info & alac::CD_VALID) || (cd[sl].info & alac::CD_ESCAPE)) continue;
-                    alac::decode_channel_task<HostWave, alac::ROLE_BOTH>(wv, dc, alac::chan_task_key(dc, cd[sl]), true, p, sizes[i], cd[sl],
+                    alac::decode_channel_task<HostWave, alac::ROLE_BOTH>(wv, dc, alac::chan_task_key(dc, cd[sl]), true, p, sizes[i], avail, cd[sl],
                                                         rows.data() + rs * sl);
                 }
                 for (uint32_t f = 0; f < pd.frames; ++f)
-                    alac::interleave_frame(dc, p, sizes[i], pd, cd, rows.data(), rs, f, o + (size_t)f * dc.num_channels * dc.bps);
+                    alac::interleave_frame(dc, p, sizes[i], avail, pd, cd, rows.data(), rs, f, o + (size_t)f * dc.num_channels * dc.bps);
                 continue;
             }
             /* ROUTE_LEGACY: fall through to the whole-packet decoder */
@@ -127,11 +149,12 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
         const uint32_t cls = variant >= 0 ? (uint32_t)variant : 3u;
         if (classes_out && variant >= 0) classes_out[i] = 1024u + cls;
         switch (cls) {
-            case alac::CLASS_NA4: status[i] = alac::decode_wave<HostWave, 4, false>(wv, dc, true, p, sizes[i], o, &frames_out[i]); break;
-            case alac::CLASS_NA6: status[i] = alac::decode_wave<HostWave, 6, false>(wv, dc, true, p, sizes[i], o, &frames_out[i]); break;
-            case alac::CLASS_NA8: status[i] = alac::decode_wave<HostWave, 8, false>(wv, dc, true, p, sizes[i], o, &frames_out[i]); break;
-            default: status[i] = alac::decode_wave<HostWave, 16, true>(wv, dc, true, p, sizes[i], o, &frames_out[i]); break;
+            case alac::CLASS_NA4: status[i] = alac::decode_wave<HostWave, 4, false>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i]); break;
+            case alac::CLASS_NA6: status[i] = alac::decode_wave<HostWave, 6, false>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i]); break;
+            case alac::CLASS_NA8: status[i] = alac::decode_wave<HostWave, 8, false>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i]); break;
+            default: status[i] = alac::decode_wave<HostWave, 16, true>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i]); break;
         }
     }
+    if (region) munmap(region, region_len);
     return 0;
 }

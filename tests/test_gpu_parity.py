@@ -12,11 +12,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _gpu_decode(dec, b_blob, offsets, sizes):
-    """Host entry (alacgpu_decode_batch): contiguous offsets[n+1] are rebuilt from the padded layout."""
+    """Host entry (alacgpu_decode_batch) on the packets laid out DENSELY (back to back, as in an mdat): every test
+    that goes through here also checks that a packet's neighbour is never read as its zero pad."""
     pk = [b_blob[int(o):int(o) + int(s)].tobytes() for o, s in zip(offsets, sizes)]
     offs = np.zeros(len(pk) + 1, np.uint64)
     offs[1:] = np.cumsum([len(p) for p in pk], dtype=np.uint64)
-    blob = np.frombuffer(b"".join(pk) + b"\0", np.uint8)
+    blob = np.frombuffer(b"".join(pk) or b"\0", np.uint8)
     return dec.decode_batch(blob, offs)
 
 
@@ -151,7 +152,7 @@ def test_device_resident_entry_full_size_round_trip(pkg, synth, oracle, gpu_deco
     d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     with gpu_decoder_factory(cfg) as dec:
-        dec.decode_batch_device(d_blob.data_ptr(), d_off.data_ptr(), d_sz.data_ptr(), n, d_out.data_ptr(), stride,
+        dec.decode_batch_device(d_blob.data_ptr(), d_blob.numel(), d_off.data_ptr(), d_sz.data_ptr(), n, d_out.data_ptr(), stride,
                                 d_fr.data_ptr(), d_st.data_ptr(), sync=True)
         assert dec.last_kernel_ms() > 0
     assert int(d_st.abs().sum()) == 0
@@ -159,6 +160,93 @@ def test_device_resident_entry_full_size_round_trip(pkg, synth, oracle, gpu_deco
     assert torch.equal(d_out.cpu(), torch.from_numpy(b.pcm))
     ref = oracle.decode_batch(cfg, b.blob, b.offsets[:256], b.sizes[:256], threads=8)
     assert np.array_equal(ref[0], d_out[:256].cpu().numpy())
+
+
+@pytest.mark.parametrize("depth,ch,fl", [(16, 2, 256), (24, 2, 128), (24, 8, 48), (32, 1, 64)])
+def test_dense_device_entry_hostile_neighbours_and_bad_descriptors(pkg, oracle, synth, helpers, gpu_decoder_factory,
+                                                                   depth, ch, fl):
+    """alacgpu_decode_batch_device on a dense blob: truncated packets whose neighbours are non-zero bytes decode as
+    if followed by the reference's zero pad (bitbuffer.go:33); descriptors that leave the blob get ALACGPU_ERR_RANGE
+    and do not disturb their neighbours; d_sizes == NULL takes the sizes from offsets[n+1]."""
+    import torch
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    rng = np.random.default_rng(depth + ch)
+    b = synth.gen_batch(cfg, 80, profile=synth.PROFILE_MUSIC, threads=8)
+    q = synth.gen_batch(cfg, 40, profile=synth.PROFILE_QUIET, threads=8)
+    packets = []
+    for src in (b, q):
+        for i in range(src.n):
+            p = src.packet(i)
+            packets += [p, p[:int(rng.integers(1, len(p)))], p[:max(1, len(p) - int(rng.integers(1, 9)))]]
+    packets += helpers.mutate_packets(b, rng, 100)
+    packets.append(b.packet(3)[:len(b.packet(3)) // 2])  # a truncated packet ends the blob
+    ref_blob, ref_offs, ref_sizes = helpers.pack_packets(packets)
+    ref = oracle.decode_batch(cfg, ref_blob, ref_offs, ref_sizes, threads=8)
+    dev = torch.device("cuda:0")
+    stride = (fl * bpf + 15) // 16 * 16
+    for lead in (0, 3):
+        blob, offs, sizes = helpers.pack_dense(packets, lead=lead)
+        n = len(packets)
+        offs1 = np.concatenate([offs, [np.uint64(len(blob))]]).astype(np.uint64)
+        d_blob = torch.from_numpy(blob).to(dev)
+        d_off = torch.from_numpy(offs1.astype(np.int64)).to(dev)
+        d_sz = torch.from_numpy(sizes.astype(np.int32)).to(dev)
+        with gpu_decoder_factory(cfg) as dec:
+            for use_sizes in (True, False):
+                d_out = torch.full((n, stride), 0xA5, dtype=torch.uint8, device=dev)
+                d_fr = torch.full((n,), -1, dtype=torch.int32, device=dev)
+                d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+                torch.cuda.synchronize()
+                dec.decode_batch_device(d_blob.data_ptr(), len(blob), d_off.data_ptr(),
+                                        d_sz.data_ptr() if use_sizes else None, n, d_out.data_ptr(), stride,
+                                        d_fr.data_ptr(), d_st.data_ptr(), sync=True)
+                got = (d_out.cpu().numpy(), d_fr.cpu().numpy().astype(np.uint32), d_st.cpu().numpy())
+                helpers.assert_same_decode(cfg, ref, got, bpf, "dense lead %d sizes %s" % (lead, use_sizes))
+            # descriptors that leave the blob: flagged, neighbours unaffected
+            bad_off = offs.copy()
+            bad_sz = sizes.copy()
+            bad_off[5] = len(blob) + 17               # starts behind the blob
+            bad_sz[9] = len(blob)                     # reaches beyond it
+            bad_off[11] = np.uint64(2 ** 63)          # nowhere near
+            bad_sz[13] = 0x7fffffff
+            d_off2 = torch.from_numpy(bad_off.astype(np.int64)).to(dev)
+            d_sz2 = torch.from_numpy(bad_sz.astype(np.int32)).to(dev)
+            d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            dec.decode_batch_device(d_blob.data_ptr(), len(blob), d_off2.data_ptr(), d_sz2.data_ptr(), n, d_out.data_ptr(),
+                                    stride, d_fr.data_ptr(), d_st.data_ptr(), sync=True)
+            st = d_st.cpu().numpy()
+            fr = d_fr.cpu().numpy()
+            for k in (5, 9, 11, 13):
+                assert st[k] == 7 and fr[k] == 0, (k, st[k])  # ALACGPU_ERR_RANGE
+            keep = np.ones(n, bool)
+            keep[[5, 9, 11, 13]] = False
+            assert np.array_equal(st[keep], ref[2][keep]) and np.array_equal(fr[keep].astype(np.uint32), ref[1][keep])
+
+
+def test_host_entry_many_chunks(pkg, oracle, synth, helpers, gpu_decoder_factory, monkeypatch):
+    """alacgpu_decode_batch cuts a batch into chunks that are in flight on three streams at once: force small chunks
+    (slots are reused many times) and check every packet, pageable and pinned caller memory."""
+    import torch
+    monkeypatch.setenv("ALACGPU_CHUNK_MB", "1")
+    cfg = oracle.make_config(1024, 16, 2)
+    b = synth.gen_batch(cfg, 3000, threads=8)
+    ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=8)
+    with gpu_decoder_factory(cfg) as dec:
+        for _ in range(2):
+            helpers.assert_same_decode(cfg, ref, _gpu_decode(dec, b.blob, b.offsets, b.sizes), 4, "pageable")
+        blob, offs, sizes = helpers.pack_dense([b.packet(i) for i in range(b.n)])
+        offs1 = np.concatenate([offs, [np.uint64(len(blob))]]).astype(np.uint64)
+        t_blob = torch.empty(len(blob), dtype=torch.uint8, pin_memory=True)
+        t_blob.numpy()[:] = blob
+        t_out = torch.empty((b.n, dec.frame_bytes), dtype=torch.uint8, pin_memory=True)
+        t_fr = torch.empty(b.n, dtype=torch.int32, pin_memory=True)
+        t_st = torch.empty(b.n, dtype=torch.int32, pin_memory=True)
+        pkg._check(dec._lib.alacgpu_decode_batch(dec._h, t_blob.data_ptr(), offs1.ctypes.data, b.n, t_out.data_ptr(),
+                                                 dec.frame_bytes, t_fr.data_ptr(), t_st.data_ptr()))
+        got = (t_out.numpy(), t_fr.numpy().view(np.uint32), t_st.numpy())
+        helpers.assert_same_decode(cfg, ref, got, 4, "pinned")
 
 
 def test_24bit_shift_and_8ch_full_frames(pkg, synth, oracle, helpers, gpu_decoder_factory):

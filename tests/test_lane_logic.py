@@ -57,3 +57,38 @@ def test_wave_pair_chunk_tails(oracle, synth, lane_sim, helpers, depth, ch, fl):
         ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=4)
         got = lane_sim(cfg, b.blob, b.offsets, b.sizes, variant=-1)
         helpers.assert_same_decode(cfg, ref, got, bpf, "profile %d" % prof)
+
+
+@pytest.mark.parametrize("depth,ch,fl", [(16, 2, 256), (24, 2, 128), (16, 1, 64), (24, 8, 48), (32, 2, 64), (20, 3, 50)])
+def test_dense_blob_with_hostile_neighbours(oracle, synth, lane_sim, helpers, depth, ch, fl):
+    """Packets back to back as in an mdat (internal/mp4/mp4.go:382-420): no zero pad, any alignment, the blob ends with
+    the last byte of the last packet. Truncated packets then have the NEXT packet's (non-zero) bytes where the
+    reference sees its 4 zero pad bytes (bitbuffer.go:33): results must not change. The blob sits against an
+    inaccessible page (guard), so a read beyond it is fatal."""
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    rng = np.random.default_rng(depth * 7 + ch)
+    for prof in (synth.PROFILE_MUSIC, synth.PROFILE_STRESS, synth.PROFILE_QUIET):
+        b = synth.gen_batch(cfg, 40, profile=prof, threads=4)
+        packets = []
+        for i in range(b.n):
+            p = b.packet(i)
+            packets.append(p)
+            packets.append(p[:int(rng.integers(1, len(p)))])          # truncated: its neighbour starts right behind it
+            packets.append(p[:max(1, len(p) - int(rng.integers(1, 9)))])  # cut inside the last bytes
+        packets += helpers.mutate_packets(b, rng, 60)
+        packets.append(b.packet(0))                                    # an intact packet ends the blob
+        ref_blob, ref_offs, ref_sizes = helpers.pack_packets(packets)
+        ref = oracle.decode_batch(cfg, ref_blob, ref_offs, ref_sizes, threads=4)
+        for lead in (0, 1, 2, 3):
+            blob, offs, sizes = helpers.pack_dense(packets, lead=lead)
+            for variant in (-1, -2, 3):
+                got = lane_sim(cfg, blob, offs, sizes, variant=variant, guard=True)
+                helpers.assert_same_decode(cfg, ref, got, bpf, "dense lead %d variant %d profile %d" % (lead, variant, prof))
+        # ... and with a truncated packet as the very last thing in the blob
+        packets.append(b.packet(1)[:len(b.packet(1)) // 2])
+        ref_blob, ref_offs, ref_sizes = helpers.pack_packets(packets)
+        ref = oracle.decode_batch(cfg, ref_blob, ref_offs, ref_sizes, threads=4)
+        blob, offs, sizes = helpers.pack_dense(packets, lead=1)
+        got = lane_sim(cfg, blob, offs, sizes, variant=-1, guard=True)
+        helpers.assert_same_decode(cfg, ref, got, bpf, "dense, truncated tail")

@@ -24,7 +24,7 @@ dec.reserve(P)
 L = ctypes.CDLL(pkg.lib_path())
 buf = (ctypes.c_ulonglong * 16)()
 def step():
-    dec.decode_batch_device(d_blob.data_ptr(), d_off.data_ptr(), d_sz.data_ptr(), P, d_out.data_ptr(), stride,
+    dec.decode_batch_device(d_blob.data_ptr(), d_blob.numel(), d_off.data_ptr(), d_sz.data_ptr(), P, d_out.data_ptr(), stride,
                             d_fr.data_ptr(), d_st.data_ptr(), sync=True)
 step(); step()
 L.alacgpu_debug_prof(buf)
