@@ -151,7 +151,9 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
         if (CPE) {
             /* matrix.go:40-41 (mixRes != 0) and :50-51 (plain copy) in one branch-free form */
             const int32_t vv = o;
-            l = u + (int32_t)((uint32_t)vv & nzm) - (ALAC_MUL24(mix_res, vv) >> mix_sh);
+            /* mixRes * v: exact on 24 bits for chanBits <= 23, int32 wrap-around otherwise (as the reference's) */
+            const int32_t mv = NARROW ? ALAC_MUL24(mix_res, vv) : (int32_t)((uint32_t)mix_res * (uint32_t)vv);
+            l = u + (int32_t)((uint32_t)vv & nzm) - (mv >> mix_sh);
             r = (int32_t)((((uint32_t)(l - vv)) & nzm) | ((uint32_t)vv & ~nzm));
         }
         if (F16) {
@@ -361,7 +363,7 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits,
                                                                        den_shift, chan_bits, mix_res, mix_sh, na,     \
                                                                        shift_pos, sb, mode);                          \
         break;
-    constexpr bool CAN_EA = OUT == OUT_STEREO || OUT == OUT_MONO; /* phases that write PCM */
+    constexpr bool CAN_EA = NARROW && (OUT == OUT_STEREO || OUT == OUT_MONO); /* phases that write PCM; not the wide ones */
     if (ROLE == ROLE_A) {
         if (CAN_EA && duo_emit_in_a(na, OUT == OUT_STEREO))
             duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, true>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
@@ -398,7 +400,7 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits,
 
 /*
  * decode_regular_duo: same contract as decode_wave (alac_wave.h) for the caller playing role A (or both):
- * every lane holds a regular packet with the same key = numU*32 + numV, lanes without a packet pass live = false;
+ * every lane holds a regular packet with the same key = numU*32 + numV (+ KEY_WIDE), lanes without a packet pass live = false;
  * returns the status word and sets *frames_out. The caller playing role B passes the same arguments; its return
  * value and *frames_out mean nothing.
  */
@@ -408,7 +410,8 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
     const BitsT<false> bits{pkt, size, avail}; /* regular packets hold at least 12 bytes (classify_regular) */
     const bool cpe = cfg.num_channels == 2;
-    const uint32_t na_u = key >> 5, na_v = key & 31u;
+    const bool wide = (key & KEY_WIDE) != 0; /* chanBits > 23: predict_wide */
+    const uint32_t na_u = (key >> 5) & 31u, na_v = key & 31u;
 
     RegLane<W> s;
     s.rd.init(pkt, size);
@@ -440,7 +443,7 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     const uint32_t sb = (cfg.bit_depth == 24 || cfg.bit_depth == 32) ? bs * 8u : 0u;
     const uint32_t n_it = wv.max_u32(ns);
     /* the stager belongs to the wave that writes the PCM of the last channel (duo_emit_in_a) */
-    const bool emit_a = duo_emit_in_a(cpe ? na_v : na_u, cpe);
+    const bool emit_a = !wide && duo_emit_in_a(cpe ? na_v : na_u, cpe);
     const bool writer = emit_a ? DO_A : DO_B;
     if (writer && live) wv.st_begin(out);
 
@@ -450,8 +453,13 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     s.zrem = 0;
     s.pb = (cfg.pb * ((hu >> 5) & 7u)) / 4u; /* decoder.go:299 */
     if (DO_A) s.rd.start(wv, live ? s.pos : 0u);
-    if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
-    else duo_phase_na<W, OUT_MONO, ROLE, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
+    if (!wide) {
+        if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
+        else duo_phase_na<W, OUT_MONO, ROLE, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
+    } else {
+        if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
+        else duo_phase_na<W, OUT_MONO, ROLE, false, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
+    }
     uint32_t err_chan = 0;
     /* ---- V ---- */
     if (cpe) {
@@ -463,7 +471,9 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
         s.zrem = 0;
         s.pb = (cfg.pb * ((hv >> 5) & 7u)) / 4u;
         if (DO_A) s.rd.start(wv, (live && s.err == 0) ? s.pos : 0u);
-        if (cfg.bit_depth == 16)
+        if (wide)
+            duo_phase_na<W, OUT_STEREO, ROLE, false, false>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+        else if (cfg.bit_depth == 16)
             duo_phase_na<W, OUT_STEREO, ROLE, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
         else
             duo_phase_na<W, OUT_STEREO, ROLE, false>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);

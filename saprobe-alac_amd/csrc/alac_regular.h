@@ -3,8 +3,9 @@
  * Golomb/Rice step and the adaptive predictor step.
  *
  * A packet is REGULAR when classify_regular() accepts it: mono or stereo, its first tag is the one element that
- * covers the whole frame (SCE/LFE for 1 channel, CPE for 2), compressed, chanBits 1..23 (16-bit; 20-bit; 24/32-bit
- * with their usual shift bytes), mode 0 on both channels, predictor orders 0..16 or 31, header inside the packet.
+ * covers the whole frame (SCE/LFE for 1 channel, CPE for 2), compressed, any legal chanBits (1..23 on 24-bit
+ * multiply-adds, 24..33 on the literal 32-bit form), mode 0 on both channels, predictor orders 0..16 or 31, header
+ * inside the packet.
  * Regular packets are decoded by a pair of wavefronts per 64 packets (alac_duo.h); everything else is scanned
  * first (decode_wave<SCAN>, alac_wave.h) and finished by the split pipeline (alac_split.h) or the whole-packet
  * decoder. All of them produce identical bytes and status words; which one runs is a speed choice made per packet
@@ -85,8 +86,10 @@
 
 namespace alac {
 
-constexpr uint32_t KEY_IRREGULAR = 1024; /* sort key of packets for decode_wave; regular: numU*32 + numV */
-constexpr uint32_t NUM_KEYS = 1025;
+/* sort key of a regular packet: numU*32 + numV, + KEY_WIDE when chanBits > 23 (the literal 32-bit predictor) */
+constexpr uint32_t KEY_WIDE = 1024;
+constexpr uint32_t KEY_IRREGULAR = 2048; /* everything else: scan first (alac_wave.h) */
+constexpr uint32_t NUM_KEYS = 2049;
 
 /* orders the lean decoder runs: 4/5/6/8 on exactly NA taps, the others (general form, int16 coefficient wrap) on
  * 16 register taps with wave-uniform skips; 0 copies and 31 is delta mode. 17..30 exist only on paper. */
@@ -107,9 +110,12 @@ ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32
     if (hdr & 1u) return KEY_IRREGULAR; /* escape element */
     const uint32_t bs = (hdr >> 1) & 3u;
     if (bs == 3) return KEY_IRREGULAR;
-    /* 24-bit products need chanBits <= 23 (16-bit; 20-bit; 24/32-bit with their usual shift bytes) */
+    /* 24-bit products need chanBits <= 23 (16-bit; 20-bit; 24/32-bit with their usual shift bytes); wider channels
+     * (24/32-bit without shift bytes: chanBits 24..33, decoder.go:371) take the same wave pair with the literal
+     * 32-bit predictor, under their own keys */
     const uint32_t chan_bits = cfg.bit_depth - 8u * bs + (cpe ? 1u : 0u);
-    if (chan_bits < 1 || chan_bits > 23 || cfg.bit_depth < 8u * bs) return KEY_IRREGULAR;
+    if (chan_bits < 1 || chan_bits > 33 || cfg.bit_depth < 8u * bs) return KEY_IRREGULAR;
+    const uint32_t wide = chan_bits > 23u ? KEY_WIDE : 0u;
     uint32_t pos = 23;
     uint32_t ns = cfg.frame_length;
     if (hdr >> 3) {
@@ -135,7 +141,7 @@ ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32
      * (Bits::window_raw) */
     const uint64_t ent = (uint64_t)pos + (uint64_t)bs * 8u * (cpe ? 2u : 1u) * ns;
     if ((ent >> 3) >= size || (bs != 0 && (ent >> 3) + 8u > size)) return KEY_IRREGULAR;
-    return nu * 32u + nv;
+    return nu * 32u + nv + wide;
 }
 
 /* ---- the lean path's bit reader: an LDS ring per lane, refilled ahead of time --------------------------------

@@ -130,11 +130,11 @@ constexpr uint32_t kFallbackSlots = 64;
 constexpr uint32_t kRingStride = 36; /* 32 ring dwords + 4: rows stay 16-byte aligned, lanes spread over banks */
 
 /* device-side launch plan, rebuilt by every decode */
-/* sort keys: 0..1023 regular packets (numU*32 + numV, alac_regular.h); 1024 / 1025 irregular packets (below). A
- * workgroup holds packets of ONE key. */
-constexpr uint32_t kKeys = 1024 + alac::NUM_CLASSES;
-constexpr uint32_t kKeyLegacy = 1024; /* decode_wave */
-constexpr uint32_t kKeyScan = 1025;   /* decode_wave<SCAN> + split pipeline */
+/* sort keys: 0..2047 regular packets (numU*32 + numV + KEY_WIDE, alac_regular.h); 2048 / 2049 irregular packets
+ * (below). A workgroup holds packets of ONE key. */
+constexpr uint32_t kKeys = alac::KEY_IRREGULAR + alac::NUM_CLASSES;
+constexpr uint32_t kKeyLegacy = alac::KEY_IRREGULAR;     /* decode_wave */
+constexpr uint32_t kKeyScan = alac::KEY_IRREGULAR + 1u;  /* decode_wave<SCAN> + split pipeline */
 struct Plan {
     uint32_t count[kKeys];     /* packets per key */
     uint32_t pkt_start[kKeys]; /* first index in perm[] */
@@ -144,7 +144,7 @@ struct Plan {
     uint32_t list_key[kKeys];
     uint32_t list_wave0[kKeys]; /* first block id */
     uint32_t total_waves;
-    uint32_t irr_waves; /* waves of the irregular keys (>= 1024): they come first */
+    uint32_t irr_waves; /* waves of the irregular keys (>= KEY_IRREGULAR): they come first */
 };
 
 /* LDS of the decode kernel (one wave per workgroup). Referenced by name, never through a generic pointer, so
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(kWave) alac_plan(Plan* plan, uint32_t ppw) {
         p += c;
         w += cw;
         z += c ? 1u : 0u;
-        wi += key >= 1024u ? cw : 0u;
+        wi += key >= alac::KEY_IRREGULAR ? cw : 0u;
     }
     /* inclusive scan over the 64 lanes, then make it exclusive */
     uint32_t ip = p, iw = w, iz = z, ii = wi;
@@ -386,7 +386,7 @@ alac_scatter(const uint16_t* __restrict__ keys, uint32_t n, Plan* plan, uint32_t
     if (i < n && key != alac::TASK_NONE) perm[base[key] + local] = i;
 }
 
-/* Irregular packets (keys >= 1024; they own the first plan->irr_waves wave slots): one wavefront per 64 packets.
+/* Irregular packets (keys >= KEY_IRREGULAR; they own the first plan->irr_waves wave slots): one wavefront per 64 packets.
  * With a usable KB they are scanned (status, frame count, channel descriptors: split pipeline step 1, PCM comes
  * from the later kernels); with KB == 0 the whole-packet decoder takes them. */
 __global__ void __launch_bounds__(kWave)
@@ -477,7 +477,7 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_by
          * kernel ends with its slowest workgroup): role B grows by nine instructions per tap, role A does not, so
          * long predictors go ahead of everything, mid-length ones level with the entropy waves, short ones behind
          * (measured on the benchmark mix: 3.15 ms with the entropy waves on top, 2.73 ms this way). */
-        const uint32_t na_max = max(ukey >> 5, ukey & 31u);
+        const uint32_t na_max = max((ukey >> 5) & 31u, ukey & 31u);
         if (na_max > 8u && na_max != 31u) __builtin_amdgcn_s_setprio(ALAC_PRIO_B_LONG);
         else if (na_max >= 6u && na_max != 31u) __builtin_amdgcn_s_setprio(ALAC_PRIO_B_MID);
         else __builtin_amdgcn_s_setprio(ALAC_PRIO_B_SHORT);
@@ -493,7 +493,7 @@ alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_by
     {
         /* where the PCM writer runs in wave A (single channels, alac_duo.h) A is the longer wave of the pair */
         const bool cpe = cfg.num_channels == 2;
-        if (alac::duo_emit_in_a(cpe ? (ukey & 31u) : (ukey >> 5), cpe)) __builtin_amdgcn_s_setprio(3);
+        if (!(ukey & alac::KEY_WIDE) && alac::duo_emit_in_a(cpe ? (ukey & 31u) : ((ukey >> 5) & 31u), cpe)) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(ALAC_PRIO_A);
     }
     const int32_t st = alac::decode_regular_duo<GpuWave, alac::ROLE_A>(wv, cfg, ukey, live, p, size, avail, o, &frames);

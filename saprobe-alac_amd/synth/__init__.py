@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 PROFILE_MUSIC, PROFILE_NOISE, PROFILE_QUIET, PROFILE_STRESS, PROFILE_MUSIC_LE8 = 0, 1, 2, 3, 4
+PROFILE_MUSIC_NOSHIFT, PROFILE_MUSIC_MIXED = 5, 6
 COEF_WARM, COEF_RANDOM, COEF_GIVEN = 0, 1, 2
 FLAG_LEADING_FIL, FLAG_MID_DSE, FLAG_NO_END = 1, 2, 4
 PACKET_PAD = 64

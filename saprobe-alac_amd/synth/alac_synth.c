@@ -537,11 +537,19 @@ void alac_synth_params(const alacgpu_config* cfg, int profile, uint64_t seed, al
             uint32_t oc = r % 100;
             int order = oc < 30 ? 4 : oc < 60 ? 6 : oc < 90 ? 8 : (oc < 95 || profile == ALAC_SYNTH_PROFILE_MUSIC_LE8) ? 5 : 12;
             ep->order_u = ep->order_v = (uint8_t)order;
+            if (profile == ALAC_SYNTH_PROFILE_MUSIC_MIXED) { /* every channel picks its own order, as ffmpeg's encoder does */
+                ep->order_u = (uint8_t)(4 + (r >> 20) % 3);
+                ep->order_v = (uint8_t)(4 + (r >> 24) % 3);
+            }
             ep->den_shift = 9;
             ep->pb_factor = 4;
             ep->mix_bits = 2;
             ep->mix_res = (int8_t)((r >> 8) % 3);
             ep->bytes_shifted = (uint8_t)(cfg->bit_depth == 24 ? 1 : cfg->bit_depth == 32 ? 2 : 0);
+            if (profile == ALAC_SYNTH_PROFILE_MUSIC_NOSHIFT) {
+                ep->bytes_shifted = 0; /* chanBits 24/25, 32/33 */
+                ep->never_escape = 1;  /* the live low bytes make the element larger than raw PCM: keep it compressed */
+            }
             ep->coef_mode = ALAC_SYNTH_COEF_WARM;
             ep->force_escape = (uint8_t)(((r >> 16) % 200) == 0); /* 0.5 % escape */
         }

@@ -20,7 +20,9 @@ enum {
     ALAC_SYNTH_PROFILE_NOISE = 1,  /* full-scale white noise: escapes */
     ALAC_SYNTH_PROFILE_QUIET = 2,  /* tiny residuals + silence: zero runs */
     ALAC_SYNTH_PROFILE_STRESS = 3, /* parity-only: random everything */
-    ALAC_SYNTH_PROFILE_MUSIC_LE8 = 4 /* MUSIC without the 5 % order-12 packets (kernel experiments) */
+    ALAC_SYNTH_PROFILE_MUSIC_LE8 = 4, /* MUSIC without the 5 % order-12 packets (kernel experiments) */
+    ALAC_SYNTH_PROFILE_MUSIC_NOSHIFT = 5, /* MUSIC with bytesShifted 0 at 24/32 bits: wide channels (chanBits 24..33) */
+    ALAC_SYNTH_PROFILE_MUSIC_MIXED = 6    /* MUSIC with independent orders 4..6 per channel (9 sort keys per batch) */
 };
 enum {
     ALAC_SYNTH_FLAG_LEADING_FIL = 1, /* FIL element before the first audio element */

@@ -92,3 +92,23 @@ def test_dense_blob_with_hostile_neighbours(oracle, synth, lane_sim, helpers, de
         blob, offs, sizes = helpers.pack_dense(packets, lead=1)
         got = lane_sim(cfg, blob, offs, sizes, variant=-1, guard=True)
         helpers.assert_same_decode(cfg, ref, got, bpf, "dense, truncated tail")
+
+
+@pytest.mark.parametrize("depth,ch,fl", [(24, 2, 300), (32, 2, 200), (24, 1, 128), (32, 1, 100)])
+def test_wide_channels_take_the_wave_pair(oracle, synth, lane_sim, helpers, depth, ch, fl):
+    """24/32-bit streams without shift bytes: chanBits 24/25 and 32/33 (decoder.go:230,371; chanShift wraps for 33,
+    predictor.go:46). classify_regular keys them KEY_WIDE and they run on the wave pair with predict_wide."""
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    for prof in (synth.PROFILE_MUSIC_NOSHIFT, synth.PROFILE_MUSIC_MIXED):
+        b = synth.gen_batch(cfg, 64, profile=prof, threads=4)
+        ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=4)
+        got = lane_sim(cfg, b.blob, b.offsets, b.sizes, variant=-1, want_classes=True)
+        helpers.assert_same_decode(cfg, ref, got[:3], bpf, "profile %d" % prof)
+        keys = got[3]
+        if prof == synth.PROFILE_MUSIC_NOSHIFT:
+            assert ((keys >= 1024) & (keys < 2048)).sum() > 48  # the wide keys, not the scan / whole-packet route
+            if depth == 24 or ch == 1:  # 32-bit pairs have chanBits 33: every sample is 0 there (predictor.go:46)
+                assert (ref[2] == 0).all() and np.array_equal(ref[0][:, :fl * bpf], b.pcm[:, :fl * bpf])
+        else:
+            assert len(np.unique(keys[keys < 1024])) >= (6 if ch == 2 else 3)
