@@ -162,12 +162,13 @@ def lib_path():
 
 
 def build(force=False):
-    """Compile csrc/alacgpu.hip for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile the translation units of csrc/ for gfx950 (hipcc cross-compiles without a GPU) and link libalacgpu.so."""
     so = lib_path()
-    srcs = [os.path.join(_CSRC, f) for f in ("alacgpu.hip", "alac_wave.h", "alac_regular.h", "alac_split.h", "alac_duo.h")] + [
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h", ".inc"))] + [
         os.path.join(_HERE, "..", "include", "alacgpu.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", _CSRC, "libalacgpu.so"], stdout=subprocess.DEVNULL)
+        jobs = str(max(1, min(6, os.cpu_count() or 1)))
+        subprocess.check_call(["make", "-C", _CSRC, "-j", jobs, "libalacgpu.so"], stdout=subprocess.DEVNULL)
     return so
 
 

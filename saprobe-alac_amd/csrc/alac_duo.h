@@ -404,13 +404,15 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits,
  * returns the status word and sets *frames_out. The caller playing role B passes the same arguments; its return
  * value and *frames_out mean nothing.
  */
-template <class W, int ROLE>
+template <class W, int ROLE, int WIDE_SEL = -1>
 ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
                                     uint32_t avail, uint8_t* out, uint32_t* frames_out) {
     constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
     const BitsT<false> bits{pkt, size, avail}; /* regular packets hold at least 12 bytes (classify_regular) */
     const bool cpe = cfg.num_channels == 2;
-    const bool wide = (key & KEY_WIDE) != 0; /* chanBits > 23: predict_wide */
+    /* chanBits > 23: predict_wide. WIDE_SEL 0 / 1: the caller only ever passes keys of that kind (the other half is
+     * not instantiated: the GPU library compiles the two halves as separate kernels, in parallel) */
+    const bool wide = WIDE_SEL < 0 ? (key & KEY_WIDE) != 0 : WIDE_SEL != 0;
     const uint32_t na_u = (key >> 5) & 31u, na_v = key & 31u;
 
     RegLane<W> s;
@@ -453,10 +455,11 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     s.zrem = 0;
     s.pb = (cfg.pb * ((hu >> 5) & 7u)) / 4u; /* decoder.go:299 */
     if (DO_A) s.rd.start(wv, live ? s.pos : 0u);
-    if (!wide) {
+    if constexpr (WIDE_SEL != 1) if (!wide) {
         if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
         else duo_phase_na<W, OUT_MONO, ROLE, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
-    } else {
+    }
+    if constexpr (WIDE_SEL != 0) if (wide) {
         if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
         else duo_phase_na<W, OUT_MONO, ROLE, false, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
     }
@@ -471,12 +474,14 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
         s.zrem = 0;
         s.pb = (cfg.pb * ((hv >> 5) & 7u)) / 4u;
         if (DO_A) s.rd.start(wv, (live && s.err == 0) ? s.pos : 0u);
-        if (wide)
+        if constexpr (WIDE_SEL != 0) if (wide)
             duo_phase_na<W, OUT_STEREO, ROLE, false, false>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
-        else if (cfg.bit_depth == 16)
-            duo_phase_na<W, OUT_STEREO, ROLE, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
-        else
-            duo_phase_na<W, OUT_STEREO, ROLE, false>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+        if constexpr (WIDE_SEL != 1) if (!wide) {
+            if (cfg.bit_depth == 16)
+                duo_phase_na<W, OUT_STEREO, ROLE, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+            else
+                duo_phase_na<W, OUT_STEREO, ROLE, false>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+        }
         if (err_u == 0 && s.err != 0) err_chan = 1;
     }
     if (writer && live) (void)wv.st_finish();

@@ -1,0 +1,305 @@
+/*
+ * alac_gpu.h — what the kernel translation units of libalacgpu.so share: the gfx950 forms of the building-block
+ * macros of alac_regular.h, the wave policies (GpuWave: LDS stager, bitstream rings, residual queue, DPP reductions;
+ * GpuWaveMem: residuals from memory), the launch plan, and the kernels' declarations. The library is built from
+ * several translation units (k_sort, k_scan, k_decode, k_decode_wide, k_split, alacgpu) so that the kernels compile in
+ * parallel; nothing crosses between them on the device side.
+ */
+#ifndef ALAC_GPU_H
+#define ALAC_GPU_H
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#define ALAC_DEV __device__ __forceinline__
+#define ALAC_NOINLINE
+#define ALAC_MUL24(a, b) __mul24((int)(a), (int)(b))
+/* |a - b| + c in one instruction. As an expression (max - min + c) the compiler shares the max / min between the
+ * unrolled steps of a chunk and ends up with three or four instructions for most taps. */
+__device__ __forceinline__ uint32_t alac_sad(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#define ALAC_SAD(a, b, c) alac_sad((uint32_t)(a), (uint32_t)(b), (uint32_t)(c))
+
+__device__ __forceinline__ int32_t alac_sign_med3(int32_t x) {
+    int32_t r;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(x));
+    return r;
+}
+#define ALAC_SIGN(x) alac_sign_med3(x)
+__device__ __forceinline__ int32_t alac_clamp01_med3(int32_t x) {
+    int32_t r;
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(r) : "v"(x));
+    return r;
+}
+#define ALAC_CLAMP01(x) alac_clamp01_med3(x)
+__device__ __forceinline__ uint32_t alac_xad(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#define ALAC_XAD(a, b, c) alac_xad((uint32_t)(a), (uint32_t)(b), (uint32_t)(c))
+__device__ __forceinline__ uint32_t alac_bfi(uint32_t m, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+#define ALAC_BFI(m, a, b) alac_bfi((uint32_t)(m), (uint32_t)(a), (uint32_t)(b))
+__device__ __forceinline__ int32_t alac_mad24(int32_t a, int32_t b, int32_t c) {
+    int32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#define ALAC_MAD24(a, b, c) alac_mad24((int32_t)(a), (int32_t)(b), (int32_t)(c))
+__device__ __forceinline__ int32_t alac_msub24(int32_t acc, int32_t a, int32_t negc) {
+    int32_t r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(negc), "v"(acc));
+    return r;
+}
+#define ALAC_MSUB24(acc, a, c) alac_msub24((int32_t)(acc), (int32_t)(a), -(int32_t)(c))
+#define ALAC_SUBSAT(a, b) __builtin_elementwise_sub_sat((uint32_t)(a), (uint32_t)(b))
+#define ALAC_MULU24(a, b) __umul24((unsigned)(a), (unsigned)(b))
+#define ALAC_PICK(dst, src) asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(src))
+#define ALAC_OWN_REG(x) asm volatile("" : "+v"(x))
+typedef uint32_t alac_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+#define ALAC_LOAD4(q, a, b, c, d)                                                       \
+    do {                                                                                \
+        const alac_u32x4_a4 v_ = *reinterpret_cast<const alac_u32x4_a4*>(q);            \
+        (a) = v_.x;                                                                     \
+        (b) = v_.y;                                                                     \
+        (c) = v_.z;                                                                     \
+        (d) = v_.w;                                                                     \
+    } while (0)
+typedef int32_t alac_i32x4 __attribute__((ext_vector_type(4)));
+#define ALAC_STORE4(q, a, b, c, d) (*reinterpret_cast<alac_i32x4*>(q) = alac_i32x4{(a), (b), (c), (d)})
+#ifdef ALAC_DUO_PROF
+/* profiling build: cycles (s_memtime) between the stamps of alac_duo.h, summed per role over all waves */
+static __device__ unsigned long long g_duo_prof[16];
+#define ALAC_DUO_STAMP(k)                                                   \
+    do {                                                                    \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
+        if ((k) > 0) wv.prof[(k) - 1] += t_ - wv.prof_t;                     \
+        wv.prof_t = t_;                                                     \
+    } while (0)
+#endif
+#include "alac_wave.h"
+#include "alac_regular.h"
+#include "alac_duo.h"
+#include "alac_split.h"
+
+/* s_setprio levels of the wave pair (see alac_decode) */
+#ifndef ALAC_PRIO_B_LONG
+#define ALAC_PRIO_B_LONG 3  /* predictor waves, order > 8 */
+#define ALAC_PRIO_B_MID 2   /* order 6..8 */
+#define ALAC_PRIO_B_SHORT 1 /* order < 6 */
+#define ALAC_PRIO_A 2       /* entropy waves */
+#endif
+
+namespace alack {
+
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kWave = 64;
+constexpr uint32_t kTimingSlots = 64;
+constexpr uint32_t kRowStride = 65; /* dwords per lane row in LDS: odd stride = conflict-free column access */
+constexpr uint32_t kRing = 64;      /* dwords of PCM a lane row holds (two 128-B chunks) */
+constexpr uint32_t kFallbackSlots = 64;
+constexpr uint32_t kRingStride = 36; /* 32 ring dwords + 4: rows stay 16-byte aligned, lanes spread over banks */
+
+/* device-side launch plan, rebuilt by every decode */
+/* sort keys: 0..2047 regular packets (numU*32 + numV + KEY_WIDE, alac_regular.h); 2048 / 2049 irregular packets
+ * (below). A workgroup holds packets of ONE key. */
+constexpr uint32_t kKeys = alac::KEY_IRREGULAR + alac::NUM_CLASSES;
+constexpr uint32_t kKeyLegacy = alac::KEY_IRREGULAR;     /* decode_wave */
+constexpr uint32_t kKeyScan = alac::KEY_IRREGULAR + 1u;  /* decode_wave<SCAN> + split pipeline */
+struct Plan {
+    uint32_t count[kKeys];     /* packets per key */
+    uint32_t pkt_start[kKeys]; /* first index in perm[] */
+    uint32_t cursor[kKeys];    /* scatter cursors */
+    /* compact list of the non-empty keys in dispatch order (slowest first) */
+    uint32_t nk;
+    uint32_t list_key[kKeys];
+    uint32_t list_wave0[kKeys]; /* first block id */
+    uint32_t total_waves;
+    uint32_t irr_waves; /* waves of the irregular keys (>= KEY_IRREGULAR): they come first */
+};
+
+/* LDS of the decode kernel (one wave per workgroup). Referenced by name, never through a generic pointer, so
+ * every access is a ds_* instruction (a pointer kept in a struct decays to flat_* loads and stores). */
+static __shared__ uint32_t s_rows[kWave * kRowStride];                                  /* PCM stager rows */
+static __shared__ unsigned long long s_optr[kWave];                                     /* PCM slot of each lane's packet */
+static __shared__ __attribute__((aligned(16))) uint32_t s_ring[kWave * kRingStride];    /* bitstream rings */
+/* residual queue of the wave pair (alac_duo.h), A -> B, double-buffered chunks */
+constexpr uint32_t kQ = alac::DUO_CHUNK;
+static __shared__ int32_t s_rq[2 * kQ * kWave];
+
+/* U hand-off tile of one wave: frame_length rows of 64 cells and one spare row (the single-wave decoders read one
+ * row ahead) */
+__host__ __device__ inline size_t u_tile_cells(uint32_t frame_length) { return ((size_t)frame_length + 1u) * kWave; }
+
+/* ---- gfx950 wave policy for alac::decode_wave --------------------------------------------------------- */
+struct GpuWave {
+    int32_t* u_tile;           /* HBM: this lane's column of the wave's U hand-off tile */
+    int32_t* g_tile;           /* HBM: this lane's column of the wave's fall-back tile */
+    uint8_t* my_out;
+    uint32_t lane, wcnt, flushed;
+    uint32_t ppw;              /* packets (= live lanes) per wave; also the row stride of the HBM tiles */
+#ifdef ALAC_DUO_PROF
+    unsigned long long prof[4] = {0, 0, 0, 0}, prof_t = 0;
+#endif
+
+    ALAC_DEV bool any(bool p) const { return __ballot(p) != 0ull; }
+    ALAC_DEV uint32_t max_u32(uint32_t v) const {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+            v = t > v ? t : v;
+        }
+        /* every lane holds the maximum: hand it back as a scalar, so loops bounded by it are uniform */
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    }
+    ALAC_DEV void st_begin(uint8_t* out) {
+        my_out = out;
+        s_optr[lane] = (unsigned long long)reinterpret_cast<uintptr_t>(out);
+        wcnt = flushed = 0;
+    }
+    ALAC_DEV void st_push(uint32_t v) {
+        s_rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
+        ++wcnt;
+    }
+    /* branch-free form: a lane that is not `on` rewrites its next free slot and does not advance */
+    ALAC_DEV void st_push_if(uint32_t v, bool on) {
+        s_rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
+        wcnt += on ? 1u : 0u;
+    }
+    /* bytes of the last, incomplete dword of the stream (after every dword pushed so far) */
+    ALAC_DEV void st_tail(uint64_t acc, uint32_t nbytes) {
+        for (uint32_t b = 0; b < nbytes; ++b) my_out[(size_t)wcnt * 4u + b] = (uint8_t)(acc >> (8u * b));
+    }
+    /* Collective. Rows that just completed a 32-dword chunk are written out as 128-B lines: store
+     * instruction k covers packets 8k..8k+7, eight lanes x 16 B per packet. Lock step makes `flushed`
+     * identical in all full lanes. */
+    ALAC_DEV void st_step() {
+        const bool full = (wcnt - flushed) >= 32u;
+        const unsigned long long mask = __ballot(full);
+        if (mask == 0ull) return;
+        __builtin_amdgcn_wave_barrier();
+        const int first = __ffsll((long long)mask) - 1;
+        const uint32_t fl = (uint32_t)__shfl((int)flushed, first, 64);
+        const uint32_t col0 = fl & (kRing - 1u);
+        const uint32_t piece = lane & 7u;
+        const uint32_t groups = (ppw + 7u) >> 3;
+        for (uint32_t k = 0; k < groups; ++k) {
+            const uint32_t q = 8u * k + (lane >> 3);
+            if ((mask >> q) & 1ull) {
+                const uint32_t* r = s_rows + q * kRowStride + col0 + piece * 4u;
+                const uint4 v = make_uint4(r[0], r[1], r[2], r[3]);
+                uint8_t* dst = reinterpret_cast<uint8_t*>((uintptr_t)s_optr[q]) + ((size_t)fl + piece * 4u) * 4u;
+                /* the address came through LDS as an integer: name the global address space, or it is a flat store */
+                *reinterpret_cast<__attribute__((address_space(1))) u32x4*>((uintptr_t)dst) = u32x4{v.x, v.y, v.z, v.w};
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (full) flushed += 32u;
+    }
+    ALAC_DEV uint32_t st_finish() {
+        for (uint32_t w = flushed; w < wcnt; ++w)
+            *reinterpret_cast<uint32_t*>(my_out + (size_t)w * 4u) = s_rows[lane * kRowStride + (w & (kRing - 1u))];
+        flushed = wcnt;
+        return wcnt;
+    }
+    /* bitstream ring of the entropy wave: 32 dwords per lane, rows of kRingStride dwords (16-byte aligned) */
+    ALAC_DEV void ring_write4(uint32_t slot, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+        /* (slot >> 2) * 4 lets the compiler see the 16-byte alignment: one ds_write_b128 */
+        *reinterpret_cast<uint4*>(&s_ring[lane * kRingStride + (slot >> 2) * 4u]) = make_uint4(a, b, c, d);
+    }
+    ALAC_DEV uint32_t ring_read(uint32_t slot) const { return s_ring[lane * kRingStride + slot]; }
+    /* residual queue: row j of buffer buf holds step j of the chunk for all 64 lanes (conflict-free) */
+    ALAC_DEV void rq_write(uint32_t buf, uint32_t j, int32_t v) { s_rq[(buf * kQ + j) * kWave + lane] = v; }
+    ALAC_DEV int32_t rq_read(uint32_t buf, uint32_t j) const { return s_rq[(buf * kQ + j) * kWave + lane]; }
+    /* chunk hand-over between the two waves of the workgroup: LDS traffic only, so outstanding global loads
+     * (ring refills, U prefetch) and stores (U tile) are NOT waited for — __syncthreads() would drain them */
+    ALAC_DEV void duo_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+    /* end of the U phase: wave B's tile stores must have landed before wave A loads them */
+    ALAC_DEV void duo_sync_mem() {
+        __threadfence_block();
+        __syncthreads();
+    }
+    /* rows of 64 cells whatever ppw is: a constant stride lets unrolled steps address their rows by immediate
+     * offsets from one base, and every lane (with or without a packet) owns a column */
+    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * kWave; }
+    ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * ppw; }
+};
+
+/* The predictor wave of the split pipeline when the residuals are already in memory (the scan left them in the
+ * task's row, scan_channel): role B of alac_duo.h with the residual "queue" read straight from the row — no entropy
+ * wave, no barrier. duo_sync() is called once per chunk iteration and moves the window on. */
+struct GpuWaveMem : GpuWave {
+    const int32_t* res; /* this lane's row: residuals in, samples out (the writer runs 32+ samples behind the reads) */
+    uint32_t it, chunk0;
+    ALAC_DEV int32_t rq_read(uint32_t, uint32_t j) const { return res[chunk0 + j]; }
+    ALAC_DEV void rq_write(uint32_t, uint32_t, int32_t) {}
+    ALAC_DEV void duo_sync() {
+        ++it;
+        chunk0 = (it - 1u) * kQ;
+    }
+    ALAC_DEV void duo_sync_mem() {}
+};
+
+/* readable bytes of the blob from a packet's start, as Bits wants them */
+__device__ __forceinline__ uint32_t avail_of(uint64_t blob_bytes, uint64_t off) {
+    const uint64_t left = blob_bytes - off;
+    return left > 0xffffffffull ? 0xffffffffu : (uint32_t)left;
+}
+
+/* ---- kernels (one decode = these launches on the handle's stream) ---- */
+__global__ void alac_classify(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
+                              const uint32_t* __restrict__ sizes, uint32_t n, uint16_t* __restrict__ keys, uint32_t* __restrict__ sizes_ws,
+                              uint32_t* __restrict__ frames_out, int32_t* __restrict__ status, Plan* plan);
+__global__ void alac_plan(Plan* plan, uint32_t ppw);
+__global__ void alac_scatter(const uint16_t* __restrict__ keys, uint32_t n, Plan* plan, uint32_t* __restrict__ perm);
+__global__ void alac_task_classify(alac::DevCfg cfg, const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd,
+                                   const uint16_t* __restrict__ pkt_keys, uint32_t n_slots, uint16_t* __restrict__ keys, Plan* plan);
+__global__ void alac_scan(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
+                          const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+                          uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
+                          int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g,
+                          uint32_t ppw, alac::ChanDesc* __restrict__ cd, alac::PktDesc* __restrict__ pd, int32_t* __restrict__ rows,
+                          uint64_t row_stride);
+__global__ void alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
+                            const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+                            const alac::PktDesc* __restrict__ pd, uint8_t* __restrict__ out, uint64_t out_stride,
+                            uint32_t* __restrict__ frames_out, int32_t* __restrict__ status, int32_t* __restrict__ scratch_u,
+                            int32_t* __restrict__ scratch_g, uint32_t ppw);
+__global__ void alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
+                            const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+                            uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
+                            int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, uint32_t ppw);
+__global__ void alac_decode_wide(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
+                                 const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+                                 uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
+                                 int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, uint32_t ppw);
+__global__ void alac_chan_predict(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
+                                  const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+                                  const alac::ChanDesc* __restrict__ cd, int32_t* __restrict__ rows, uint64_t row_stride, uint32_t ppw);
+__global__ void alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
+                                const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+                                const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd, const int32_t* __restrict__ rows,
+                                uint64_t row_stride, uint8_t* __restrict__ out, uint64_t out_stride, uint32_t blocks_per_pkt);
+
+} /* namespace alack */
+#endif

@@ -39,6 +39,16 @@
         (d) = (q)[3];            \
     } while (0)
 #endif
+#ifndef ALAC_STORE4
+/* four consecutive dwords to a 16-byte aligned address: one global_store_dwordx4 on the GPU */
+#define ALAC_STORE4(q, a, b, c, d) \
+    do {                          \
+        (q)[0] = (a);             \
+        (q)[1] = (b);             \
+        (q)[2] = (c);             \
+        (q)[3] = (d);             \
+    } while (0)
+#endif
 #ifndef ALAC_PICK
 /* dst = src, opaque to the optimiser on the GPU: a chain of these under scalar tests must stay a chain of
  * v_mov (written plainly the compiler turns it into an indexed load from a scratch copy of the array) */
@@ -482,10 +492,14 @@ enum { OUT_UTILE = 0,  /* U of a pair: hand-off tile */
        OUT_MONO = 2,   /* single channel: PCM */
        OUT_RAW = 3 };  /* int32 samples into this lane's row (split pipeline, alac_split.h) */
 
-/* Entropy scan of one channel for decode_wave<..., SCAN>: the lean Golomb loop with nothing behind it. */
+/* Entropy scan of one channel for decode_wave<..., SCAN>: the lean Golomb loop. With res_row (wave-uniform: all
+ * lanes or none) the residuals are kept: four per 16-byte store into the lane's row, so that the split pipeline's
+ * predictor pass (alac_split.h) does not have to decode the stream a second time. Rows hold frame_length + 3 samples
+ * rounded up to 4, lanes write whole groups of four up to the wave's longest channel (ns <= frame_length). */
 template <class W, class B>
 ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_t* pkt, uint32_t size, bool go,
-                           uint32_t& pos, uint32_t ns, uint32_t pb_local, uint32_t chan_bits, int32_t& err) {
+                           uint32_t& pos, uint32_t ns, uint32_t pb_local, uint32_t chan_bits, int32_t& err,
+                           int32_t* res_row) {
     RegLane<W> s;
     s.rd.init(pkt, size);
     s.err = 0;
@@ -497,19 +511,31 @@ ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_
     s.pb = pb_local;
     const uint32_t my_ns = go ? ns : 0u;
     const uint32_t n_it = wv.max_u32(my_ns);
-    const uint32_t kb = cfg.kb, wb = go_shl(1u, kb) - 1u; /* golomb.go:60 */
+    uint32_t kb = cfg.kb;
+    ALAC_OWN_REG(kb);
+    const uint32_t wb = go_shl(1u, kb) - 1u; /* golomb.go:60 */
     s.rd.start(wv, s.pos);
     uint32_t ns_live = my_ns;
     uint32_t on_mask = (uint32_t)((int32_t)(0u - ns_live) >> 31);
+    const bool keep = res_row != nullptr;
+    /* the four residuals of a group are stored at the top of the NEXT group, right behind the ring's top-up: vector
+     * memory operations retire in order (vmcnt), so a store issued just before a top-up's wait would make the entropy
+     * chain wait for the store's round trip; issued right after it, it has four steps to drain */
+    int32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
     uint32_t i = 0;
     for (; i + 4u <= n_it; i += 4u) { /* four steps per ring top-up, straight-line */
         s.rd.tick(wv);
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) (void)gol_step(wv, bits, s, size, kb, wb, chan_bits, i + j, my_ns, ns_live, on_mask);
+        if (keep && go && i != 0u) ALAC_STORE4(res_row + (i - 4u), h0, h1, h2, h3);
+        h0 = gol_step(wv, bits, s, size, kb, wb, chan_bits, i, my_ns, ns_live, on_mask);
+        h1 = gol_step(wv, bits, s, size, kb, wb, chan_bits, i + 1u, my_ns, ns_live, on_mask);
+        h2 = gol_step(wv, bits, s, size, kb, wb, chan_bits, i + 2u, my_ns, ns_live, on_mask);
+        h3 = gol_step(wv, bits, s, size, kb, wb, chan_bits, i + 3u, my_ns, ns_live, on_mask);
     }
+    if (keep && go && i != 0u) ALAC_STORE4(res_row + (i - 4u), h0, h1, h2, h3);
     for (; i < n_it; ++i) {
         if ((i & 3u) == 0) s.rd.tick(wv);
-        (void)gol_step(wv, bits, s, size, kb, wb, chan_bits, i, my_ns, ns_live, on_mask);
+        const int32_t d = gol_step(wv, bits, s, size, kb, wb, chan_bits, i, my_ns, ns_live, on_mask);
+        if (keep && go) res_row[i] = d;
     }
     if (go) {
         pos = s.pos;

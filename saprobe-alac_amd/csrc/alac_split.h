@@ -124,5 +124,90 @@ ALAC_DEV void interleave_frame(const DevCfg& cfg, const uint8_t* pkt, uint32_t s
             for (uint32_t k = 0; k < bps; ++k) frame[sidx * bps + k] = 0;
 }
 
+/* The same frame for the layouts whose frames are whole dwords (NC channels x BPS bytes, NC * BPS % 4 == 0), built in
+ * registers: slot s of an NC-channel stream always lands in output channel layout_offset(NC, s) (decoder.go:55-64),
+ * so with the slots unrolled every byte position is a compile-time constant — no byte stores, no per-byte address
+ * arithmetic. f[] receives the frame as little-endian dwords; channels nobody wrote stay zero (decoder.go:120,127). */
+template <int NC, int BPS>
+ALAC_DEV void interleave_frame_packed(const DevCfg& cfg, const uint8_t* pkt, uint32_t size, uint32_t avail, const PktDesc& pd,
+                                      const ChanDesc* cd, const int32_t* rows, size_t row_stride, uint32_t i,
+                                      uint32_t (&f)[NC * BPS / 4]) {
+    static_assert((NC * BPS) % 4 == 0, "whole dwords only");
+    constexpr uint32_t MASK = BPS == 4 ? 0xffffffffu : ((1u << (8 * (BPS & 3))) - 1u);
+    const Bits bits{pkt, size, avail};
+#pragma unroll
+    for (int k = 0; k < NC * BPS / 4; ++k) f[k] = 0;
+    /* later elements overwrite earlier ones where a (non-standard) element order makes them meet, as the reference's
+     * sequential writes do: replace, not OR */
+    auto put = [&](auto off_c, int32_t v) {
+        constexpr int OFF = decltype(off_c)::value; /* byte offset inside the frame */
+        constexpr int D = OFF / 4, SH = 8 * (OFF % 4);
+        constexpr uint32_t M0 = MASK << SH;
+        const uint32_t u = (uint32_t)v & MASK;
+        f[D] = (f[D] & ~M0) | (u << SH);
+        if (SH + 8 * BPS > 32) {
+            constexpr uint32_t M1 = SH ? (MASK >> ((32 - SH) & 31)) : 0u;
+            f[D + 1 < NC * BPS / 4 ? D + 1 : D] = (f[D + 1 < NC * BPS / 4 ? D + 1 : D] & ~M1) | (u >> ((32 - SH) & 31));
+        }
+    };
+    auto emit_at = [&](int chan, int32_t v) { /* chan is a constant after unrolling: the switch folds */
+        switch (chan) {
+            case 0: put(std::integral_constant<int, 0>{}, v); break;
+            case 1: put(std::integral_constant<int, (NC > 1 ? 1 : 0) * BPS>{}, v); break;
+            case 2: put(std::integral_constant<int, (NC > 2 ? 2 : 0) * BPS>{}, v); break;
+            case 3: put(std::integral_constant<int, (NC > 3 ? 3 : 0) * BPS>{}, v); break;
+            case 4: put(std::integral_constant<int, (NC > 4 ? 4 : 0) * BPS>{}, v); break;
+            case 5: put(std::integral_constant<int, (NC > 5 ? 5 : 0) * BPS>{}, v); break;
+            case 6: put(std::integral_constant<int, (NC > 6 ? 6 : 0) * BPS>{}, v); break;
+            case 7: put(std::integral_constant<int, (NC > 7 ? 7 : 0) * BPS>{}, v); break;
+            default: break; /* a pair in the last slot: the scan calls that malformed, such packets do not get here */
+        }
+    };
+    const uint32_t depth = cfg.bit_depth;
+#pragma unroll
+    for (int slot = 0; slot < NC; ++slot) {
+        constexpr uint32_t tbl[8] = {0x0u, 0x10u, 0x102u, 0x3102u, 0x43102u, 0x354102u, 0x3654102u, 0x35410762u};
+        const int out_chan = (int)((tbl[NC - 1] >> (4 * slot)) & 0xfu);
+        if ((uint32_t)slot >= pd.nslots) continue;
+        const ChanDesc d = cd[slot];
+        if (!(d.info & CD_VALID) || (d.info & CD_SECOND) || i >= d.ns) continue;
+        const bool cpe = (d.info & CD_CPE) != 0, escape = (d.info & CD_ESCAPE) != 0;
+        const uint32_t nch_e = cpe ? 2u : 1u;
+        const uint32_t chan_bits = (d.info >> CD_CHANBITS_SHIFT) & 63u;
+        const uint32_t sb = (d.info >> CD_SB_SHIFT) & 31u;
+        int32_t a, b = 0;
+        if (escape) { /* decodeSCEEscape / decodeCPEEscape, decoder.go:326-345 / 507-535 */
+            const uint32_t cs = 32u - chan_bits;
+            a = sext_cs((int32_t)bits.get(d.hdr_pos + (i * nch_e) * chan_bits, chan_bits), cs);
+            if (cpe) b = sext_cs((int32_t)bits.get(d.hdr_pos + (i * nch_e + 1u) * chan_bits, chan_bits), cs);
+        } else {
+            a = rows[(size_t)slot * row_stride + i];
+            if (cpe && slot + 1 < NC) b = rows[(size_t)(slot + 1) * row_stride + i];
+        }
+        int32_t l = a, r = 0;
+        if (cpe) {
+            const int32_t mix_res = (int32_t)(int8_t)(d.mix & 0xff);
+            const uint32_t mix_sh = ((uint32_t)d.mix >> 8) & 31u;
+            if (mix_res != 0) { /* matrix.go:40-41 */
+                l = a + b - ((mix_res * b) >> mix_sh);
+                r = l - b;
+            } else {
+                r = b;
+            }
+        }
+        if (depth == 20) { /* matrix.go:77-78, 237 */
+            l = (int32_t)((uint32_t)l << 4);
+            r = (int32_t)((uint32_t)r << 4);
+        }
+        if (sb) { /* matrix.go:129-132, 266-268: both shift values of a frame lie side by side (decoder.go:492-502) */
+            const uint64_t w = bits.window(d.shift_pos + i * nch_e * sb);
+            l = (int32_t)((uint32_t)l << sb) | (int32_t)(uint32_t)(w >> (64u - sb));
+            if (cpe) r = (int32_t)((uint32_t)r << sb) | (int32_t)(uint32_t)((w << sb) >> (64u - sb));
+        }
+        emit_at(out_chan, l);
+        if (cpe) emit_at(out_chan + 1, r); /* R goes right behind L (matrix.go:31-32), whatever the layout says about the next slot */
+    }
+}
+
 } /* namespace alac */
 #endif

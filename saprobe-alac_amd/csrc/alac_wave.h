@@ -260,7 +260,8 @@ enum { ROUTE_NONE = 0, ROUTE_SPLIT = 1, ROUTE_LEGACY = 2 };
 /* Golomb-only pass over one channel (defined in alac_regular.h): advances pos to the end of the entropy stream */
 template <class W, class B>
 ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_t* pkt, uint32_t size, bool go,
-                           uint32_t& pos, uint32_t ns, uint32_t pb_local, uint32_t chan_bits, int32_t& err);
+                           uint32_t& pos, uint32_t ns, uint32_t pb_local, uint32_t chan_bits, int32_t& err,
+                           int32_t* res_row);
 
 /* ------------------------------------------------------------------------------------------------------
  * decode_wave<W, NA, WRAP>: every lane of the wave calls this with its own packet (live = false for lanes
@@ -278,7 +279,10 @@ ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_
  * ------------------------------------------------------------------------------------------------------ */
 template <class W, int NA, bool WRAP, bool SCAN = false>
 ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t* pkt, uint32_t size, uint32_t avail,
-                             uint8_t* out, uint32_t* frames_out, ChanDesc* cd = nullptr, PktDesc* pd = nullptr) {
+                             uint8_t* out, uint32_t* frames_out, ChanDesc* cd = nullptr, PktDesc* pd = nullptr,
+                             int32_t* res_rows = nullptr, size_t res_stride = 0) {
+    /* res_rows (SCAN, more than two channels): this packet's sample rows; the scan leaves every compressed channel's
+     * residuals in the row of its slot for the predictor pass (wave-uniform: null for all lanes or for none) */
     /* SCAN: walk the packet exactly like a decode (same errors in the same order) but only find where every
      * channel's entropy stream starts and ends (scan_channel), describe the channels in cd[0..7] and the packet
      * in *pd; no prediction, no PCM. */
@@ -514,7 +518,8 @@ ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t*
             int32_t dprev = 0; /* delta pre-pass state (mode != 0) */
             if (SCAN) {
                 int32_t e2 = 0;
-                scan_channel(wv, cfg, bits, pkt, size, run && !escape && ns != 0, pos, ns, pb_local, chan_bits, e2);
+                scan_channel(wv, cfg, bits, pkt, size, run && !escape && ns != 0, pos, ns, pb_local, chan_bits, e2,
+                             res_rows ? res_rows + (size_t)umin(chan_idx + c, 7u) * res_stride : nullptr);
                 if (run && e2) {
                     err = e2;
                     err_chan = c;

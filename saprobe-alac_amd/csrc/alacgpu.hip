@@ -9,656 +9,24 @@
  *   alac_classify  one thread per packet: sort key from the first element header (a few bytes read)
  *   alac_plan      one wavefront: key histogram -> packet / wave ranges (irregular keys, then the longest predictors)
  *   alac_scatter   one thread per packet: counting-sort scatter into the lane permutation
- *   alac_scan      irregular packets, one wavefront per 64: status, frame count, where each channel starts
- *   alac_decode    regular packets: a PAIR of wavefronts per 64 same-key packets (alac_duo.h): entropy wave and
- *                  predictor / PCM wave, residuals through an LDS queue; PCM staged in LDS, written as 128-B lines
- *   alac_task_classify / alac_plan / alac_scatter / alac_chan_decode   (> 2 channels) the same pair per 64
- *                  (packet, channel) tasks the scan found, int32 rows
+ *   alac_scan      irregular packets, one wavefront per 64: status, frame count, where each channel starts; with
+ *                  more than two channels also every channel's residuals, into the channel's row
+ *   alac_decode / alac_decode_wide   regular packets: a PAIR of wavefronts per 64 same-key packets (alac_duo.h):
+ *                  entropy wave and predictor / PCM wave, residuals through an LDS queue; PCM staged in LDS, written
+ *                  as 128-B lines (two kernels: chanBits <= 23 and wider, one compilation unit each)
+ *   alac_task_classify / alac_plan / alac_scatter / alac_chan_predict   (> 2 channels) one wavefront per 64
+ *                  (packet, channel) tasks of the same order: the predictor over the stored residuals, in place
  *   alac_interleave, alac_legacy   PCM of the scanned packets (frame order), whole-packet decoder for the rest
+ * The kernels live in k_sort.hip, k_scan.hip, k_decode.hip, k_decode_wide.hip and k_split.hip (alac_gpu.h).
  * HBM traffic per packet: compressed bytes in, PCM bytes out, plus the U-channel hand-off tile of stereo pairs
  * ((frame_length + 1) x 64 x int32 per workgroup, row-coalesced, written once and read once) or the sample rows
  * of the split pipeline.
  */
-#include <hip/hip_runtime.h>
+#include "alac_gpu.h"
 
-#include <algorithm>
-#include <atomic>
-#include <condition_variable>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <functional>
-#include <mutex>
-#include <new>
-#include <thread>
-#include <vector>
-
-#define ALAC_DEV __device__ __forceinline__
-#define ALAC_NOINLINE
-#define ALAC_MUL24(a, b) __mul24((int)(a), (int)(b))
-/* |a - b| + c in one instruction. As an expression (max - min + c) the compiler shares the max / min between the
- * unrolled steps of a chunk and ends up with three or four instructions for most taps. */
-__device__ __forceinline__ uint32_t alac_sad(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-#define ALAC_SAD(a, b, c) alac_sad((uint32_t)(a), (uint32_t)(b), (uint32_t)(c))
-
-__device__ __forceinline__ int32_t alac_sign_med3(int32_t x) {
-    int32_t r;
-    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(x));
-    return r;
-}
-#define ALAC_SIGN(x) alac_sign_med3(x)
-__device__ __forceinline__ int32_t alac_clamp01_med3(int32_t x) {
-    int32_t r;
-    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(r) : "v"(x));
-    return r;
-}
-#define ALAC_CLAMP01(x) alac_clamp01_med3(x)
-__device__ __forceinline__ uint32_t alac_xad(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-#define ALAC_XAD(a, b, c) alac_xad((uint32_t)(a), (uint32_t)(b), (uint32_t)(c))
-__device__ __forceinline__ uint32_t alac_bfi(uint32_t m, uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
-    return r;
-}
-#define ALAC_BFI(m, a, b) alac_bfi((uint32_t)(m), (uint32_t)(a), (uint32_t)(b))
-__device__ __forceinline__ int32_t alac_mad24(int32_t a, int32_t b, int32_t c) {
-    int32_t r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-#define ALAC_MAD24(a, b, c) alac_mad24((int32_t)(a), (int32_t)(b), (int32_t)(c))
-__device__ __forceinline__ int32_t alac_msub24(int32_t acc, int32_t a, int32_t negc) {
-    int32_t r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(negc), "v"(acc));
-    return r;
-}
-#define ALAC_MSUB24(acc, a, c) alac_msub24((int32_t)(acc), (int32_t)(a), -(int32_t)(c))
-#define ALAC_SUBSAT(a, b) __builtin_elementwise_sub_sat((uint32_t)(a), (uint32_t)(b))
-#define ALAC_MULU24(a, b) __umul24((unsigned)(a), (unsigned)(b))
-#define ALAC_PICK(dst, src) asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(src))
-#define ALAC_OWN_REG(x) asm volatile("" : "+v"(x))
-typedef uint32_t alac_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-#define ALAC_LOAD4(q, a, b, c, d)                                                       \
-    do {                                                                                \
-        const alac_u32x4_a4 v_ = *reinterpret_cast<const alac_u32x4_a4*>(q);            \
-        (a) = v_.x;                                                                     \
-        (b) = v_.y;                                                                     \
-        (c) = v_.z;                                                                     \
-        (d) = v_.w;                                                                     \
-    } while (0)
-#ifdef ALAC_DUO_PROF
-/* profiling build: cycles (s_memtime) between the stamps of alac_duo.h, summed per role over all waves */
-__device__ unsigned long long g_duo_prof[16];
-#define ALAC_DUO_STAMP(k)                                                   \
-    do {                                                                    \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
-        if ((k) > 0) wv.prof[(k) - 1] += t_ - wv.prof_t;                     \
-        wv.prof_t = t_;                                                     \
-    } while (0)
-#endif
-#include "alac_wave.h"
-#include "alac_regular.h"
-#include "alac_duo.h"
-#include "alac_split.h"
-
-/* s_setprio levels of the wave pair (see alac_decode) */
-#ifndef ALAC_PRIO_B_LONG
-#define ALAC_PRIO_B_LONG 3  /* predictor waves, order > 8 */
-#define ALAC_PRIO_B_MID 2   /* order 6..8 */
-#define ALAC_PRIO_B_SHORT 1 /* order < 6 */
-#define ALAC_PRIO_A 2       /* entropy waves */
-#endif
+using namespace alack;
 
 namespace {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr uint32_t kWave = 64;
-constexpr uint32_t kTimingSlots = 64;
-constexpr uint32_t kRowStride = 65; /* dwords per lane row in LDS: odd stride = conflict-free column access */
-constexpr uint32_t kRing = 64;      /* dwords of PCM a lane row holds (two 128-B chunks) */
-constexpr uint32_t kFallbackSlots = 64;
-constexpr uint32_t kRingStride = 36; /* 32 ring dwords + 4: rows stay 16-byte aligned, lanes spread over banks */
-
-/* device-side launch plan, rebuilt by every decode */
-/* sort keys: 0..2047 regular packets (numU*32 + numV + KEY_WIDE, alac_regular.h); 2048 / 2049 irregular packets
- * (below). A workgroup holds packets of ONE key. */
-constexpr uint32_t kKeys = alac::KEY_IRREGULAR + alac::NUM_CLASSES;
-constexpr uint32_t kKeyLegacy = alac::KEY_IRREGULAR;     /* decode_wave */
-constexpr uint32_t kKeyScan = alac::KEY_IRREGULAR + 1u;  /* decode_wave<SCAN> + split pipeline */
-struct Plan {
-    uint32_t count[kKeys];     /* packets per key */
-    uint32_t pkt_start[kKeys]; /* first index in perm[] */
-    uint32_t cursor[kKeys];    /* scatter cursors */
-    /* compact list of the non-empty keys in dispatch order (slowest first) */
-    uint32_t nk;
-    uint32_t list_key[kKeys];
-    uint32_t list_wave0[kKeys]; /* first block id */
-    uint32_t total_waves;
-    uint32_t irr_waves; /* waves of the irregular keys (>= KEY_IRREGULAR): they come first */
-};
-
-/* LDS of the decode kernel (one wave per workgroup). Referenced by name, never through a generic pointer, so
- * every access is a ds_* instruction (a pointer kept in a struct decays to flat_* loads and stores). */
-__shared__ uint32_t s_rows[kWave * kRowStride];                                  /* PCM stager rows */
-__shared__ unsigned long long s_optr[kWave];                                     /* PCM slot of each lane's packet */
-__shared__ __attribute__((aligned(16))) uint32_t s_ring[kWave * kRingStride];    /* bitstream rings */
-/* residual queue of the wave pair (alac_duo.h), A -> B, double-buffered chunks */
-constexpr uint32_t kQ = alac::DUO_CHUNK;
-__shared__ int32_t s_rq[2 * kQ * kWave];
-
-/* U hand-off tile of one wave: frame_length rows of 64 cells and one spare row (the single-wave decoders read one
- * row ahead) */
-__host__ __device__ inline size_t u_tile_cells(uint32_t frame_length) { return ((size_t)frame_length + 1u) * kWave; }
-
-/* ---- gfx950 wave policy for alac::decode_wave --------------------------------------------------------- */
-struct GpuWave {
-    int32_t* u_tile;           /* HBM: this lane's column of the wave's U hand-off tile */
-    int32_t* g_tile;           /* HBM: this lane's column of the wave's fall-back tile */
-    uint8_t* my_out;
-    uint32_t lane, wcnt, flushed;
-    uint32_t ppw;              /* packets (= live lanes) per wave; also the row stride of the HBM tiles */
-#ifdef ALAC_DUO_PROF
-    unsigned long long prof[4] = {0, 0, 0, 0}, prof_t = 0;
-#endif
-
-    ALAC_DEV bool any(bool p) const { return __ballot(p) != 0ull; }
-    ALAC_DEV uint32_t max_u32(uint32_t v) const {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
-            v = t > v ? t : v;
-        }
-        /* every lane holds the maximum: hand it back as a scalar, so loops bounded by it are uniform */
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-    }
-    ALAC_DEV void st_begin(uint8_t* out) {
-        my_out = out;
-        s_optr[lane] = (unsigned long long)reinterpret_cast<uintptr_t>(out);
-        wcnt = flushed = 0;
-    }
-    ALAC_DEV void st_push(uint32_t v) {
-        s_rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
-        ++wcnt;
-    }
-    /* branch-free form: a lane that is not `on` rewrites its next free slot and does not advance */
-    ALAC_DEV void st_push_if(uint32_t v, bool on) {
-        s_rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
-        wcnt += on ? 1u : 0u;
-    }
-    /* bytes of the last, incomplete dword of the stream (after every dword pushed so far) */
-    ALAC_DEV void st_tail(uint64_t acc, uint32_t nbytes) {
-        for (uint32_t b = 0; b < nbytes; ++b) my_out[(size_t)wcnt * 4u + b] = (uint8_t)(acc >> (8u * b));
-    }
-    /* Collective. Rows that just completed a 32-dword chunk are written out as 128-B lines: store
-     * instruction k covers packets 8k..8k+7, eight lanes x 16 B per packet. Lock step makes `flushed`
-     * identical in all full lanes. */
-    ALAC_DEV void st_step() {
-        const bool full = (wcnt - flushed) >= 32u;
-        const unsigned long long mask = __ballot(full);
-        if (mask == 0ull) return;
-        __builtin_amdgcn_wave_barrier();
-        const int first = __ffsll((long long)mask) - 1;
-        const uint32_t fl = (uint32_t)__shfl((int)flushed, first, 64);
-        const uint32_t col0 = fl & (kRing - 1u);
-        const uint32_t piece = lane & 7u;
-        const uint32_t groups = (ppw + 7u) >> 3;
-        for (uint32_t k = 0; k < groups; ++k) {
-            const uint32_t q = 8u * k + (lane >> 3);
-            if ((mask >> q) & 1ull) {
-                const uint32_t* r = s_rows + q * kRowStride + col0 + piece * 4u;
-                const uint4 v = make_uint4(r[0], r[1], r[2], r[3]);
-                uint8_t* dst = reinterpret_cast<uint8_t*>((uintptr_t)s_optr[q]) + ((size_t)fl + piece * 4u) * 4u;
-                /* the address came through LDS as an integer: name the global address space, or it is a flat store */
-                *reinterpret_cast<__attribute__((address_space(1))) u32x4*>((uintptr_t)dst) = u32x4{v.x, v.y, v.z, v.w};
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (full) flushed += 32u;
-    }
-    ALAC_DEV uint32_t st_finish() {
-        for (uint32_t w = flushed; w < wcnt; ++w)
-            *reinterpret_cast<uint32_t*>(my_out + (size_t)w * 4u) = s_rows[lane * kRowStride + (w & (kRing - 1u))];
-        flushed = wcnt;
-        return wcnt;
-    }
-    /* bitstream ring of the entropy wave: 32 dwords per lane, rows of kRingStride dwords (16-byte aligned) */
-    ALAC_DEV void ring_write4(uint32_t slot, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-        /* (slot >> 2) * 4 lets the compiler see the 16-byte alignment: one ds_write_b128 */
-        *reinterpret_cast<uint4*>(&s_ring[lane * kRingStride + (slot >> 2) * 4u]) = make_uint4(a, b, c, d);
-    }
-    ALAC_DEV uint32_t ring_read(uint32_t slot) const { return s_ring[lane * kRingStride + slot]; }
-    /* residual queue: row j of buffer buf holds step j of the chunk for all 64 lanes (conflict-free) */
-    ALAC_DEV void rq_write(uint32_t buf, uint32_t j, int32_t v) { s_rq[(buf * kQ + j) * kWave + lane] = v; }
-    ALAC_DEV int32_t rq_read(uint32_t buf, uint32_t j) const { return s_rq[(buf * kQ + j) * kWave + lane]; }
-    /* chunk hand-over between the two waves of the workgroup: LDS traffic only, so outstanding global loads
-     * (ring refills, U prefetch) and stores (U tile) are NOT waited for — __syncthreads() would drain them */
-    ALAC_DEV void duo_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-    /* end of the U phase: wave B's tile stores must have landed before wave A loads them */
-    ALAC_DEV void duo_sync_mem() {
-        __threadfence_block();
-        __syncthreads();
-    }
-    /* rows of 64 cells whatever ppw is: a constant stride lets unrolled steps address their rows by immediate
-     * offsets from one base, and every lane (with or without a packet) owns a column */
-    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * kWave; }
-    ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * ppw; }
-};
-
-/* readable bytes of the blob from a packet's start, as Bits wants them */
-__device__ __forceinline__ uint32_t avail_of(uint64_t blob_bytes, uint64_t off) {
-    const uint64_t left = blob_bytes - off;
-    return left > 0xffffffffull ? 0xffffffffu : (uint32_t)left;
-}
-
-/* Packet descriptors are checked here, once: a packet must lie inside the blob (the caller's offsets and sizes are
- * untrusted device data). One that does not gets ALACGPU_ERR_RANGE, no sort key, and is never looked at again; the
- * sizes every later kernel uses are the checked copies in sizes_ws. d_sizes may be null: packet i is then
- * blob[offsets[i], offsets[i+1]) (the host entry's offsets[n+1]).
- * Sort-key histogram of one 256-thread block in LDS; only the keys the block saw go to the global counters
- * (a batch has a dozen distinct keys: per-packet global atomics on them serialise). */
-__global__ void __launch_bounds__(256)
-alac_classify(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
-              const uint32_t* __restrict__ sizes, uint32_t n, uint16_t* __restrict__ keys, uint32_t* __restrict__ sizes_ws,
-              uint32_t* __restrict__ frames_out, int32_t* __restrict__ status, Plan* plan) {
-    __shared__ uint32_t hist[kKeys];
-    for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x) hist[k] = 0;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const uint64_t off = offsets[i];
-        uint64_t sz = sizes ? (uint64_t)sizes[i] : offsets[i + 1] - off;
-        const bool ok = off <= blob_bytes && sz <= blob_bytes - off && sz <= 0x0fffffffull &&
-                        (sizes || offsets[i + 1] >= off);
-        if (!ok) {
-            keys[i] = (uint16_t)alac::TASK_NONE;
-            sizes_ws[i] = 0;
-            frames_out[i] = 0;
-            status[i] = ALACGPU_ERR_RANGE;
-        } else if (sz == 0) {
-            /* an empty packet: PastEnd before the first tag (decoder.go:143-145). Settled here so that the readers
-             * only ever see packets of at least one byte (their loads are anchored on the packet's last byte). */
-            keys[i] = (uint16_t)alac::TASK_NONE;
-            sizes_ws[i] = 0;
-            frames_out[i] = 0;
-            status[i] = ALACGPU_STATUS(alac::ST_OVERRUN, 0, 0);
-        } else {
-            sizes_ws[i] = (uint32_t)sz;
-            const uint8_t* p = blob + off;
-            uint32_t key = alac::classify_regular(cfg, p, (uint32_t)sz, avail_of(blob_bytes, off));
-            /* not regular: scan first (with a usable KB). More than two channels: split pipeline. One or two: escape
-             * elements are unpacked by alac_interleave, anything else is handed to the whole-packet decoder. */
-            if (key == alac::KEY_IRREGULAR) key = cfg.kb != 0 ? kKeyScan : kKeyLegacy;
-            keys[i] = (uint16_t)key;
-            atomicAdd(&hist[key], 1u);
-        }
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x)
-        if (hist[k]) atomicAdd(&plan->count[k], hist[k]);
-}
-
-/* One wavefront: exclusive scan of the key histogram in dispatch order (highest key first: irregular packets, then
- * the longest predictors; a kernel ends when its last wave does, so the slowest waves get the lowest block ids).
- * Each lane owns a run of consecutive dispatch positions; the lane totals are scanned with shuffles. */
-__global__ void __launch_bounds__(kWave) alac_plan(Plan* plan, uint32_t ppw) {
-    __shared__ uint32_t cnt[kKeys];
-    for (uint32_t k = threadIdx.x; k < kKeys; k += kWave) cnt[k] = plan->count[k];
-    __syncthreads();
-    constexpr uint32_t R = (kKeys + kWave - 1) / kWave;
-    const uint32_t q0 = threadIdx.x * R; /* dispatch position q holds key kKeys - 1 - q */
-    uint32_t p = 0, w = 0, z = 0, wi = 0;
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t q = q0 + r;
-        if (q >= kKeys) break;
-        const uint32_t key = kKeys - 1u - q;
-        const uint32_t c = cnt[key];
-        const uint32_t cw = (c + ppw - 1) / ppw;
-        p += c;
-        w += cw;
-        z += c ? 1u : 0u;
-        wi += key >= alac::KEY_IRREGULAR ? cw : 0u;
-    }
-    /* inclusive scan over the 64 lanes, then make it exclusive */
-    uint32_t ip = p, iw = w, iz = z, ii = wi;
-#pragma unroll
-    for (int o = 1; o < (int)kWave; o <<= 1) {
-        const uint32_t tp = (uint32_t)__shfl_up((int)ip, o, kWave), tw = (uint32_t)__shfl_up((int)iw, o, kWave);
-        const uint32_t tz = (uint32_t)__shfl_up((int)iz, o, kWave), ti = (uint32_t)__shfl_up((int)ii, o, kWave);
-        if ((int)threadIdx.x >= o) {
-            ip += tp;
-            iw += tw;
-            iz += tz;
-            ii += ti;
-        }
-    }
-    uint32_t ep = ip - p, ew = iw - w, ez = iz - z;
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t q = q0 + r;
-        if (q >= kKeys) break;
-        const uint32_t key = kKeys - 1u - q;
-        const uint32_t c = cnt[key];
-        plan->pkt_start[key] = ep;
-        plan->cursor[key] = 0;
-        if (c) {
-            plan->list_key[ez] = key;
-            plan->list_wave0[ez] = ew;
-            ++ez;
-            ep += c;
-            ew += (c + ppw - 1) / ppw;
-        }
-    }
-    if (threadIdx.x == kWave - 1u) {
-        plan->nk = iz;
-        plan->total_waves = iw;
-        plan->irr_waves = ii;
-    }
-}
-
-/* Counting-sort scatter. A block reserves one range per key it holds with a single global atomic and hands out
- * the slots inside it from LDS. The order of packets inside a key is arbitrary (and may differ run to run);
- * results do not depend on it. */
-__global__ void __launch_bounds__(256)
-alac_scatter(const uint16_t* __restrict__ keys, uint32_t n, Plan* plan, uint32_t* __restrict__ perm) {
-    __shared__ uint32_t hist[kKeys];
-    __shared__ uint32_t base[kKeys];
-    for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x) hist[k] = 0;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t key = 0, local = 0;
-    if (i < n) {
-        key = keys[i];
-        if (key != alac::TASK_NONE) local = atomicAdd(&hist[key], 1u);
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < kKeys; k += blockDim.x)
-        if (hist[k]) base[k] = plan->pkt_start[k] + atomicAdd(&plan->cursor[k], hist[k]);
-    __syncthreads();
-    if (i < n && key != alac::TASK_NONE) perm[base[key] + local] = i;
-}
-
-/* Irregular packets (keys >= KEY_IRREGULAR; they own the first plan->irr_waves wave slots): one wavefront per 64 packets.
- * With a usable KB they are scanned (status, frame count, channel descriptors: split pipeline step 1, PCM comes
- * from the later kernels); with KB == 0 the whole-packet decoder takes them. */
-__global__ void __launch_bounds__(kWave)
-alac_scan(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
-          const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
-          uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
-          int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g,
-          uint32_t ppw, alac::ChanDesc* __restrict__ cd, alac::PktDesc* __restrict__ pd) {
-    const uint32_t b = blockIdx.x;
-    if (b >= plan->irr_waves) return;
-    uint32_t e = 0;
-    for (uint32_t t = 1; t < plan->nk; ++t)
-        if (plan->list_wave0[t] <= b) e = t;
-    const uint32_t key = plan->list_key[e];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t idx = (b - plan->list_wave0[e]) * ppw + lane;
-    const bool live = lane < ppw && idx < plan->count[key];
-    const uint32_t pkt = live ? perm[plan->pkt_start[key] + idx] : 0u;
-
-    GpuWave wv;
-    wv.u_tile = scratch_u + (size_t)b * u_tile_cells(cfg.frame_length) + lane;
-    wv.g_tile = scratch_g + (size_t)b * kFallbackSlots * ppw + lane;
-    wv.ppw = ppw;
-    wv.my_out = nullptr;
-    wv.lane = lane;
-    wv.wcnt = wv.flushed = 0;
-
-    /* lanes without a packet read nothing (size 0) */
-    const uint64_t off = live ? offsets[pkt] : 0ull;
-    const uint8_t* p = blob + off;
-    const uint32_t size = live ? sizes[pkt] : 0u;
-    const uint32_t avail = avail_of(blob_bytes, off);
-    uint8_t* o = out + (size_t)pkt * out_stride;
-    uint32_t frames = 0;
-    int32_t st;
-    const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
-    if (ukey == kKeyScan)
-        st = alac::decode_wave<GpuWave, 16, true, true>(wv, cfg, live, p, size, avail, o, &frames, cd + (size_t)pkt * 8u, pd + pkt);
-    else
-        st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, avail, o, &frames);
-    if (live) {
-        frames_out[pkt] = frames;
-        status[pkt] = st;
-    }
-}
-
-/* Regular packets: a pair of wavefronts per 64 packets with the SAME key (alac_duo.h): wave 0 = role A (entropy),
- * wave 1 = role B (predictor + PCM), lane = packet in both. Two waves per SIMD (four workgroups per CU) is what
- * the pair is built for: the register budget is capped there. */
-__global__ void __launch_bounds__(2 * kWave, 2)
-alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
-            const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
-            uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
-            int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, uint32_t ppw) {
-    const uint32_t b = blockIdx.x + plan->irr_waves;
-    if (b >= plan->total_waves) return;
-    /* which key owns wave slot b: last list entry whose first wave is <= b (a handful of entries) */
-    uint32_t e = 0;
-    for (uint32_t t = 1; t < plan->nk; ++t)
-        if (plan->list_wave0[t] <= b) e = t;
-    const uint32_t key = plan->list_key[e];
-    const uint32_t lane = threadIdx.x & (kWave - 1u);
-    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t idx = (b - plan->list_wave0[e]) * ppw + lane;
-    const bool live = lane < ppw && idx < plan->count[key];
-    const uint32_t pkt = live ? perm[plan->pkt_start[key] + idx] : 0u;
-
-    GpuWave wv;
-    /* U tile: a column per lane (the decoders store without a branch, so lanes without a packet need cells too) */
-    wv.u_tile = scratch_u + (size_t)b * u_tile_cells(cfg.frame_length) + lane;
-    wv.g_tile = nullptr;
-    wv.ppw = ppw;
-    wv.my_out = nullptr;
-    wv.lane = lane;
-    wv.wcnt = wv.flushed = 0;
-
-    /* lanes without a packet read nothing (size 0) */
-    const uint64_t off = live ? offsets[pkt] : 0ull;
-    const uint8_t* p = blob + off;
-    const uint32_t size = live ? sizes[pkt] : 0u;
-    const uint32_t avail = avail_of(blob_bytes, off);
-    uint8_t* o = out + (size_t)pkt * out_stride;
-    uint32_t frames = 0;
-    /* the key is wave-uniform (one key per workgroup): scalar branches pick the variant */
-    const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
-    if (role != 0u) {
-        /* Issue priority goes to whichever wave is the longer one of its pair, and among pairs to the slowest (the
-         * kernel ends with its slowest workgroup): role B grows by nine instructions per tap, role A does not, so
-         * long predictors go ahead of everything, mid-length ones level with the entropy waves, short ones behind
-         * (measured on the benchmark mix: 3.15 ms with the entropy waves on top, 2.73 ms this way). */
-        const uint32_t na_max = max((ukey >> 5) & 31u, ukey & 31u);
-        if (na_max > 8u && na_max != 31u) __builtin_amdgcn_s_setprio(ALAC_PRIO_B_LONG);
-        else if (na_max >= 6u && na_max != 31u) __builtin_amdgcn_s_setprio(ALAC_PRIO_B_MID);
-        else __builtin_amdgcn_s_setprio(ALAC_PRIO_B_SHORT);
-        (void)alac::decode_regular_duo<GpuWave, alac::ROLE_B>(wv, cfg, ukey, live, p, size, avail, o, &frames);
-#ifdef ALAC_DUO_PROF
-        if (lane == 0)
-            for (int k = 0; k < 4; ++k) atomicAdd(&g_duo_prof[8 + k], wv.prof[k]);
-#endif
-        return;
-    }
-    /* the entropy chain is serial: it issues whenever it can, shorter predictor waves (many independent
-     * instructions) fill the slots in between */
-    {
-        /* where the PCM writer runs in wave A (single channels, alac_duo.h) A is the longer wave of the pair */
-        const bool cpe = cfg.num_channels == 2;
-        if (!(ukey & alac::KEY_WIDE) && alac::duo_emit_in_a(cpe ? (ukey & 31u) : ((ukey >> 5) & 31u), cpe)) __builtin_amdgcn_s_setprio(3);
-        else __builtin_amdgcn_s_setprio(ALAC_PRIO_A);
-    }
-    const int32_t st = alac::decode_regular_duo<GpuWave, alac::ROLE_A>(wv, cfg, ukey, live, p, size, avail, o, &frames);
-#ifdef ALAC_DUO_PROF
-    if (lane == 0)
-        for (int k = 0; k < 4; ++k) atomicAdd(&g_duo_prof[k], wv.prof[k]);
-#endif
-    if (live) {
-        frames_out[pkt] = frames;
-        status[pkt] = st;
-    }
-}
-
-/* ---- split pipeline (alac_split.h) -------------------------------------------------------------------- */
-/* one thread per (packet, bitstream channel): sort key of the channel task, or TASK_NONE */
-__global__ void __launch_bounds__(256)
-alac_task_classify(alac::DevCfg cfg, const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd,
-                   const uint16_t* __restrict__ pkt_keys, uint32_t n_slots, uint16_t* __restrict__ keys, Plan* plan) {
-    __shared__ uint32_t hist[alac::NUM_TASK_KEYS];
-    if (threadIdx.x < alac::NUM_TASK_KEYS) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_slots) {
-        const uint32_t pkt = t >> 3, slot = t & 7u;
-        uint32_t key = alac::TASK_NONE;
-        if (pkt_keys[pkt] == kKeyScan) {
-            const alac::PktDesc q = pd[pkt];
-            if (q.status == 0 && q.route == alac::ROUTE_SPLIT && slot < q.nslots) {
-                const alac::ChanDesc d = cd[t];
-                if ((d.info & alac::CD_VALID) && !(d.info & alac::CD_ESCAPE)) key = alac::chan_task_key(cfg, d);
-            }
-        }
-        keys[t] = (uint16_t)key;
-        if (key != alac::TASK_NONE) atomicAdd(&hist[key], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < alac::NUM_TASK_KEYS && hist[threadIdx.x]) atomicAdd(&plan->count[threadIdx.x], hist[threadIdx.x]);
-}
-
-/* a wave pair per 64 channel tasks with the same key: int32 samples of the channel into its row */
-__global__ void __launch_bounds__(2 * kWave, 2)
-alac_chan_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
-                 const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
-                 const alac::ChanDesc* __restrict__ cd, int32_t* __restrict__ rows, uint64_t row_stride, uint32_t ppw) {
-    const uint32_t b = blockIdx.x;
-    if (b >= plan->total_waves) return;
-    uint32_t e = 0;
-    for (uint32_t t = 1; t < plan->nk; ++t)
-        if (plan->list_wave0[t] <= b) e = t;
-    const uint32_t key = plan->list_key[e];
-    const uint32_t lane = threadIdx.x & (kWave - 1u);
-    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t idx = (b - plan->list_wave0[e]) * ppw + lane;
-    const bool live = lane < ppw && idx < plan->count[key];
-    const uint32_t t = live ? perm[plan->pkt_start[key] + idx] : 0u;
-    const uint32_t pkt = t >> 3, slot = t & 7u;
-
-    GpuWave wv;
-    wv.u_tile = nullptr;
-    wv.g_tile = nullptr;
-    wv.ppw = ppw;
-    wv.my_out = nullptr;
-    wv.lane = lane;
-    wv.wcnt = wv.flushed = 0;
-
-    /* lanes without a packet read nothing (size 0) */
-    const uint64_t off = live ? offsets[pkt] : 0ull;
-    const uint8_t* p = blob + off;
-    const uint32_t size = live ? sizes[pkt] : 0u;
-    const uint32_t avail = avail_of(blob_bytes, off);
-    alac::ChanDesc d = cd[t];
-    if (!live) d.hdr_pos = d.ent_pos = d.ns = 0;
-    int32_t* row = rows + ((size_t)pkt * cfg.num_channels + slot) * row_stride;
-    const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
-    if (role != 0u) {
-        const uint32_t na = ukey & 31u; /* same priorities as alac_decode */
-        if (na > 8u && na != 31u) __builtin_amdgcn_s_setprio(ALAC_PRIO_B_LONG);
-        else if (na >= 6u && na != 31u) __builtin_amdgcn_s_setprio(ALAC_PRIO_B_MID);
-        else __builtin_amdgcn_s_setprio(ALAC_PRIO_B_SHORT);
-        alac::decode_channel_task<GpuWave, alac::ROLE_B>(wv, cfg, ukey, live, p, size, avail, d, row);
-        return;
-    }
-    __builtin_amdgcn_s_setprio(ALAC_PRIO_A);
-    alac::decode_channel_task<GpuWave, alac::ROLE_A>(wv, cfg, ukey, live, p, size, avail, d, row);
-}
-
-/* one thread per (packet, frame) of the split packets: PCM in frame order. Blocks stride over the scanned
- * packets (the tail of the permutation that belongs to kKeyScan) x 256-frame slices. A slice is assembled in LDS
- * (a frame is 1..32 bytes at a byte offset of its own) and copied out as 16-byte pieces, whole lines at a time. */
-__global__ void __launch_bounds__(256)
-alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
-                const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
-                const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd, const int32_t* __restrict__ rows,
-                uint64_t row_stride, uint8_t* __restrict__ out, uint64_t out_stride, uint32_t blocks_per_pkt) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_slice[256 * 32];
-    const uint32_t n_scan = plan->count[kKeyScan];
-    const uint32_t first = plan->pkt_start[kKeyScan];
-    const uint64_t items = (uint64_t)n_scan * blocks_per_pkt;
-    const uint32_t fb = cfg.num_channels * cfg.bps;
-    for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
-        const uint32_t pkt = perm[first + (uint32_t)(it / blocks_per_pkt)];
-        const alac::PktDesc q = pd[pkt];
-        if (q.status != 0 || q.route != alac::ROUTE_SPLIT) continue; /* block-uniform */
-        const uint32_t f0 = (uint32_t)(it % blocks_per_pkt) * blockDim.x;
-        if (f0 >= q.frames) continue;
-        const uint32_t nf = min(q.frames - f0, (uint32_t)blockDim.x);
-        const uint32_t f = f0 + threadIdx.x;
-        if (threadIdx.x < nf)
-            alac::interleave_frame(cfg, blob + offsets[pkt], sizes[pkt], avail_of(blob_bytes, offsets[pkt]), q, cd + (size_t)pkt * 8u,
-                                   rows + (size_t)pkt * cfg.num_channels * row_stride, (size_t)row_stride, f,
-                                   s_slice + threadIdx.x * fb);
-        __syncthreads();
-        uint8_t* dst = out + (size_t)pkt * out_stride + (size_t)f0 * fb; /* f0 * fb is a multiple of 256 */
-        const uint32_t total = nf * fb;
-        if (cfg.aligned16) {
-            for (uint32_t k = threadIdx.x * 16u; k + 16u <= total; k += 256u * 16u)
-                *reinterpret_cast<uint4*>(dst + k) = *reinterpret_cast<const uint4*>(s_slice + k);
-            for (uint32_t k = (total & ~15u) + threadIdx.x; k < total; k += 256u) dst[k] = s_slice[k];
-        } else {
-            for (uint32_t k = threadIdx.x; k < total; k += 256u) dst[k] = s_slice[k];
-        }
-        __syncthreads();
-    }
-}
-
-/* packets the scan routed to the whole-packet decoder (orders 17..30): same wave mapping as alac_decode */
-__global__ void __launch_bounds__(kWave)
-alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
-            const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
-            const alac::PktDesc* __restrict__ pd, uint8_t* __restrict__ out, uint64_t out_stride,
-            uint32_t* __restrict__ frames_out, int32_t* __restrict__ status, int32_t* __restrict__ scratch_u,
-            int32_t* __restrict__ scratch_g, uint32_t ppw) {
-    const uint32_t b = blockIdx.x;
-    if (b >= plan->total_waves) return;
-    uint32_t e = 0;
-    for (uint32_t t = 1; t < plan->nk; ++t)
-        if (plan->list_wave0[t] <= b) e = t;
-    const uint32_t key = plan->list_key[e];
-    if (key != kKeyScan) return;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t idx = (b - plan->list_wave0[e]) * ppw + lane;
-    const bool in_wave = lane < ppw && idx < plan->count[key];
-    const uint32_t pkt = in_wave ? perm[plan->pkt_start[key] + idx] : 0u;
-    const bool live = in_wave && pd[pkt].status == 0 && pd[pkt].route == alac::ROUTE_LEGACY;
-    if (__ballot(live) == 0ull) return;
-
-    GpuWave wv;
-    wv.u_tile = scratch_u + (size_t)b * u_tile_cells(cfg.frame_length) + lane;
-    wv.g_tile = scratch_g + (size_t)b * kFallbackSlots * ppw + lane;
-    wv.ppw = ppw;
-    wv.my_out = nullptr;
-    wv.lane = lane;
-    wv.wcnt = wv.flushed = 0;
-    /* lanes without a packet read nothing (size 0) */
-    const uint64_t off = live ? offsets[pkt] : 0ull;
-    const uint8_t* p = blob + off;
-    const uint32_t size = live ? sizes[pkt] : 0u;
-    const uint32_t avail = avail_of(blob_bytes, off);
-    uint32_t frames = 0;
-    const int32_t st = alac::decode_wave<GpuWave, 16, true>(wv, cfg, live, p, size, avail, out + (size_t)pkt * out_stride, &frames);
-    if (live) {
-        frames_out[pkt] = frames;
-        status[pkt] = st;
-    }
-}
 
 thread_local char g_err[512] = "";
 
@@ -911,11 +279,18 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
     hipLaunchKernelGGL(alac_scan, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, blob_bytes,
                        d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride, d_frames,
                        d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw, (alac::ChanDesc*)dec->cd.p,
-                       (alac::PktDesc*)dec->pd.p);
-    if (dec->cfg.num_channels <= 2 && dec->cfg.kb != 0)
+                       (alac::PktDesc*)dec->pd.p, dec->cfg.num_channels > 2 ? (int32_t*)dec->rows.p : (int32_t*)nullptr,
+                       (uint64_t)row_stride_of(dec->cfg.frame_length));
+    if (dec->cfg.num_channels <= 2 && dec->cfg.kb != 0) {
         hipLaunchKernelGGL(alac_decode, dim3((uint32_t)max_waves(n, ppw)), dim3(2 * kWave), 0, dec->stream, c, d_blob,
                            blob_bytes, d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out,
                            (uint64_t)out_stride, d_frames, d_status, (int32_t*)dec->scratch_u.p, ppw);
+        /* chanBits > 23 only exists at 24 and 32 bits (without their usual shift bytes) */
+        if (dec->cfg.bit_depth >= 24)
+            hipLaunchKernelGGL(alac_decode_wide, dim3((uint32_t)max_waves(n, ppw)), dim3(2 * kWave), 0, dec->stream, c, d_blob,
+                               blob_bytes, d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out,
+                               (uint64_t)out_stride, d_frames, d_status, (int32_t*)dec->scratch_u.p, ppw);
+    }
     HIP_TRY(hipGetLastError());
     if (dec->cfg.kb != 0) {
         /* irregular packets were only scanned by alac_scan (status, frames, channel descriptors) */
@@ -934,7 +309,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
             hipLaunchKernelGGL(alac_plan, dim3(1), dim3(kWave), 0, dec->stream, plan2, ppw2);
             hipLaunchKernelGGL(alac_scatter, dim3(nb2), dim3(256), 0, dec->stream, (const uint16_t*)dec->keys2.p,
                                (uint32_t)n_slots, plan2, (uint32_t*)dec->perm2.p);
-            hipLaunchKernelGGL(alac_chan_decode, dim3((uint32_t)max_waves(n_slots, ppw2)), dim3(2 * kWave), 0, dec->stream, c,
+            hipLaunchKernelGGL(alac_chan_predict, dim3((uint32_t)max_waves(n_slots, ppw2)), dim3(kWave), 0, dec->stream, c,
                                d_blob, blob_bytes, d_offsets, sz, (const uint32_t*)dec->perm2.p, (const Plan*)plan2,
                                (const alac::ChanDesc*)dec->cd.p, (int32_t*)dec->rows.p, rs, ppw2);
         }

@@ -1,0 +1,107 @@
+/*
+ * k_split.hip — split pipeline behind the scan: predictor pass over the stored residuals, interleave (one translation unit of libalacgpu.so, see alac_gpu.h).
+ */
+#include "alac_gpu.h"
+
+namespace alack {
+
+/* Split pipeline, predictor pass: one wavefront per 64 channel tasks with the same key; the residuals are in the
+ * task's row (left there by alac_scan), the samples replace them. */
+__global__ void __launch_bounds__(kWave, 2)
+alac_chan_predict(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
+                  const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+                  const alac::ChanDesc* __restrict__ cd, int32_t* __restrict__ rows, uint64_t row_stride, uint32_t ppw) {
+    const uint32_t b = blockIdx.x;
+    if (b >= plan->total_waves) return;
+    uint32_t e = 0;
+    for (uint32_t t = 1; t < plan->nk; ++t)
+        if (plan->list_wave0[t] <= b) e = t;
+    const uint32_t key = plan->list_key[e];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t idx = (b - plan->list_wave0[e]) * ppw + lane;
+    const bool live = lane < ppw && idx < plan->count[key];
+    const uint32_t t = live ? perm[plan->pkt_start[key] + idx] : 0u;
+    const uint32_t pkt = t >> 3, slot = t & 7u;
+
+    GpuWaveMem wv;
+    wv.u_tile = nullptr;
+    wv.g_tile = nullptr;
+    wv.ppw = ppw;
+    wv.my_out = nullptr;
+    wv.lane = lane;
+    wv.wcnt = wv.flushed = 0;
+    wv.it = 0;
+    wv.chunk0 = 0;
+
+    const uint64_t off = live ? offsets[pkt] : 0ull;
+    const uint8_t* p = blob + off;
+    const uint32_t size = live ? sizes[pkt] : 0u;
+    const uint32_t avail = avail_of(blob_bytes, off);
+    alac::ChanDesc d = cd[t];
+    if (!live) d.hdr_pos = d.ent_pos = d.ns = 0;
+    /* lanes without a task read and write row 0 of packet 0's slot... no: they get the wave's first live row and
+     * neither read anything they use nor write (ns = 0) */
+    int32_t* row = rows + ((size_t)pkt * cfg.num_channels + slot) * row_stride;
+    wv.res = row;
+    const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+    alac::decode_channel_task<GpuWaveMem, alac::ROLE_B>(wv, cfg, ukey, live, p, size, avail, d, row);
+}
+
+/* one thread per (packet, frame) of the split packets: PCM in frame order. Blocks stride over the scanned
+ * packets (the tail of the permutation that belongs to kKeyScan) x 256-frame slices. A slice is assembled in LDS
+ * (a frame is 1..32 bytes at a byte offset of its own) and copied out as 16-byte pieces, whole lines at a time. */
+__global__ void __launch_bounds__(256)
+alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
+                const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+                const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd, const int32_t* __restrict__ rows,
+                uint64_t row_stride, uint8_t* __restrict__ out, uint64_t out_stride, uint32_t blocks_per_pkt) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_slice[256 * 32];
+    const uint32_t n_scan = plan->count[kKeyScan];
+    const uint32_t first = plan->pkt_start[kKeyScan];
+    const uint64_t items = (uint64_t)n_scan * blocks_per_pkt;
+    const uint32_t fb = cfg.num_channels * cfg.bps;
+    for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const uint32_t pkt = perm[first + (uint32_t)(it / blocks_per_pkt)];
+        const alac::PktDesc q = pd[pkt];
+        if (q.status != 0 || q.route != alac::ROUTE_SPLIT) continue; /* block-uniform */
+        const uint32_t f0 = (uint32_t)(it % blocks_per_pkt) * blockDim.x;
+        if (f0 >= q.frames) continue;
+        const uint32_t nf = min(q.frames - f0, (uint32_t)blockDim.x);
+        const uint32_t f = f0 + threadIdx.x;
+        if (threadIdx.x < nf) {
+            const uint8_t* pk = blob + offsets[pkt];
+            const uint32_t psz = sizes[pkt], pav = avail_of(blob_bytes, offsets[pkt]);
+            const alac::ChanDesc* pcd = cd + (size_t)pkt * 8u;
+            const int32_t* prow = rows + (size_t)pkt * cfg.num_channels * row_stride;
+            /* frames of whole dwords are built in registers (compile-time byte positions) and stored as dwords */
+#define ALAC_IL_CASE(NC_, BPS_)                                                                                        \
+    case (NC_) * 8 + (BPS_): {                                                                                         \
+        uint32_t fr[(NC_) * (BPS_) / 4];                                                                               \
+        alac::interleave_frame_packed<NC_, BPS_>(cfg, pk, psz, pav, q, pcd, prow, (size_t)row_stride, f, fr);          \
+        uint32_t* dw = reinterpret_cast<uint32_t*>(s_slice) + threadIdx.x * ((NC_) * (BPS_) / 4);                      \
+        _Pragma("unroll") for (int k = 0; k < (NC_) * (BPS_) / 4; ++k) dw[k] = fr[k];                                  \
+        break;                                                                                                         \
+    }
+            switch (cfg.num_channels * 8u + cfg.bps) {
+                ALAC_IL_CASE(4, 2) ALAC_IL_CASE(6, 2) ALAC_IL_CASE(8, 2) ALAC_IL_CASE(4, 3) ALAC_IL_CASE(8, 3)
+                ALAC_IL_CASE(3, 4) ALAC_IL_CASE(4, 4) ALAC_IL_CASE(5, 4) ALAC_IL_CASE(6, 4) ALAC_IL_CASE(7, 4) ALAC_IL_CASE(8, 4)
+                default:
+                    alac::interleave_frame(cfg, pk, psz, pav, q, pcd, prow, (size_t)row_stride, f, s_slice + threadIdx.x * fb);
+            }
+#undef ALAC_IL_CASE
+        }
+        __syncthreads();
+        uint8_t* dst = out + (size_t)pkt * out_stride + (size_t)f0 * fb; /* f0 * fb is a multiple of 256 */
+        const uint32_t total = nf * fb;
+        if (cfg.aligned16) {
+            for (uint32_t k = threadIdx.x * 16u; k + 16u <= total; k += 256u * 16u)
+                *reinterpret_cast<uint4*>(dst + k) = *reinterpret_cast<const uint4*>(s_slice + k);
+            for (uint32_t k = (total & ~15u) + threadIdx.x; k < total; k += 256u) dst[k] = s_slice[k];
+        } else {
+            for (uint32_t k = threadIdx.x; k < total; k += 256u) dst[k] = s_slice[k];
+        }
+        __syncthreads();
+    }
+}
+
+} /* namespace alack */

@@ -64,6 +64,21 @@ struct HostWave {
     int32_t* g_slot(uint32_t k) { return &g_tile[k]; }
 };
 
+/* role B alone, residuals read from the row the scan left them in (GpuWaveMem of alacgpu.hip). The host stager
+ * writes a sample the moment it is pushed; the reads run ahead of the writes (sample i is written after residual i
+ * was read), as on the GPU. */
+struct HostWaveMem : HostWave {
+    const int32_t* res = nullptr;
+    uint32_t it = 0, chunk0 = 0;
+    explicit HostWaveMem(uint32_t frame_length) : HostWave(frame_length) {}
+    int32_t rq_read(uint32_t, uint32_t j) const { return res[chunk0 + j]; }
+    void rq_write(uint32_t, uint32_t, int32_t) {}
+    void duo_sync() {
+        ++it;
+        chunk0 = (it - 1u) * alac::DUO_CHUNK;
+    }
+};
+
 }  // namespace
 
 /* variant: 0..3 = force that class's generic variant (any class must decode any packet correctly);
@@ -129,19 +144,44 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
             alac::ChanDesc cd[8];
             memset(cd, 0, sizeof(cd));
             alac::PktDesc pd{};
-            status[i] = alac::decode_wave<HostWave, 16, true, true>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i], cd, &pd);
+            /* as on the GPU: with more than two channels the scan leaves the residuals in the rows */
+            const size_t rs = (cfg->frame_length + 3u) & ~3u;
+            std::vector<int32_t> rows(rs * 8, 0x5a5a5a5a);
+            const bool keep_res = dc.num_channels > 2;
+            status[i] = alac::decode_wave<HostWave, 16, true, true>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i], cd, &pd,
+                                                                    keep_res ? rows.data() : nullptr, rs);
             if (classes_out) classes_out[i] = 2048u + pd.route;
             if (status[i] != 0) continue;
             if (pd.route == alac::ROUTE_SPLIT) {
-                const size_t rs = (cfg->frame_length + 3u) & ~3u;
-                std::vector<int32_t> rows(rs * 8, 0x5a5a5a5a);
                 for (uint32_t sl = 0; sl < pd.nslots; ++sl) {
                     if (!(cd[sl].info & alac::CD_VALID) || (cd[sl].info & alac::CD_ESCAPE)) continue;
-                    alac::decode_channel_task<HostWave, alac::ROLE_BOTH>(wv, dc, alac::chan_task_key(dc, cd[sl]), true, p, sizes[i], avail, cd[sl],
-                                                        rows.data() + rs * sl);
+                    if (keep_res) { /* predictor pass over the stored residuals (alac_chan_predict) */
+                        HostWaveMem wm(cfg->frame_length);
+                        wm.res = rows.data() + rs * sl;
+                        alac::decode_channel_task<HostWaveMem, alac::ROLE_B>(wm, dc, alac::chan_task_key(dc, cd[sl]), true, p, sizes[i],
+                                                                             avail, cd[sl], rows.data() + rs * sl);
+                    } else {
+                        alac::decode_channel_task<HostWave, alac::ROLE_BOTH>(wv, dc, alac::chan_task_key(dc, cd[sl]), true, p, sizes[i],
+                                                                              avail, cd[sl], rows.data() + rs * sl);
+                    }
                 }
-                for (uint32_t f = 0; f < pd.frames; ++f)
-                    alac::interleave_frame(dc, p, sizes[i], avail, pd, cd, rows.data(), rs, f, o + (size_t)f * dc.num_channels * dc.bps);
+                for (uint32_t f = 0; f < pd.frames; ++f) {
+                    uint8_t* dst = o + (size_t)f * dc.num_channels * dc.bps;
+                    /* the register-packed form for frames of whole dwords, as alac_interleave picks it */
+#define LANE_IL_CASE(NC_, BPS_)                                                                               \
+    case (NC_) * 8 + (BPS_): {                                                                                \
+        uint32_t fr[(NC_) * (BPS_) / 4];                                                                      \
+        alac::interleave_frame_packed<NC_, BPS_>(dc, p, sizes[i], avail, pd, cd, rows.data(), rs, f, fr);     \
+        memcpy(dst, fr, sizeof(fr));                                                                          \
+        break;                                                                                                \
+    }
+                    switch (dc.num_channels * 8u + dc.bps) {
+                        LANE_IL_CASE(4, 2) LANE_IL_CASE(6, 2) LANE_IL_CASE(8, 2) LANE_IL_CASE(4, 3) LANE_IL_CASE(8, 3)
+                        LANE_IL_CASE(3, 4) LANE_IL_CASE(4, 4) LANE_IL_CASE(5, 4) LANE_IL_CASE(6, 4) LANE_IL_CASE(7, 4) LANE_IL_CASE(8, 4)
+                        default: alac::interleave_frame(dc, p, sizes[i], avail, pd, cd, rows.data(), rs, f, dst);
+                    }
+#undef LANE_IL_CASE
+                }
                 continue;
             }
             /* ROUTE_LEGACY: fall through to the whole-packet decoder */

@@ -4,7 +4,9 @@ import numpy as np
 import pytest
 
 CONFIGS = [(16, 2, 4096), (24, 2, 1024), (16, 1, 512), (24, 8, 256), (20, 3, 300), (32, 2, 512), (16, 5, 33),
-           (32, 1, 100), (20, 2, 64), (16, 7, 40), (24, 4, 77), (16, 2, 1)]
+           (32, 1, 100), (20, 2, 64), (16, 7, 40), (24, 4, 77), (16, 2, 1),
+           # every layout whose frame is a whole number of dwords (interleave_frame_packed)
+           (16, 4, 40), (16, 6, 64), (16, 8, 48), (32, 3, 30), (32, 4, 36), (32, 5, 24), (32, 6, 28), (32, 7, 20), (32, 8, 24)]
 
 
 @pytest.mark.parametrize("depth,ch,fl", CONFIGS)
@@ -26,7 +28,8 @@ def test_lane_matches_oracle_on_valid_streams(oracle, synth, lane_sim, helpers, 
 @pytest.mark.parametrize("depth,ch,fl,kb", [(16, 2, 256, 14), (24, 2, 128, 14), (16, 1, 64, 14), (24, 8, 32, 14),
                                             (20, 3, 50, 14), (32, 2, 64, 14), (16, 5, 33, 14), (16, 2, 256, 0),
                                             (24, 6, 16, 3), (16, 2, 8, 255), (32, 8, 5, 14), (16, 2, 256, 32),
-                                            (16, 2, 256, 255), (24, 5, 64, 40)])
+                                            (16, 2, 256, 255), (24, 5, 64, 40), (16, 6, 40, 14),
+                                            (16, 8, 24, 14), (32, 4, 20, 14), (24, 4, 32, 14), (32, 7, 16, 14)])
 def test_lane_matches_oracle_on_corrupt_packets(oracle, synth, lane_sim, helpers, depth, ch, fl, kb):
     cfg = oracle.make_config(fl, depth, ch, kb=kb)
     bpf = ch * oracle.bytes_per_sample(depth)
