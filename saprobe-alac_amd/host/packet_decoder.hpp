@@ -37,12 +37,12 @@ inline std::string StatusText(int32_t st) {  // the reference's error chain, dec
     static const char* code[] = {"ok", "alac: bitstream overrun", "alac: sample count exceeds buffer",
                                  "alac: invalid frame header", "alac: invalid bytesShifted value",
                                  "alac: unsupported element type (CCE/PCE)",
-                                 "alac: malformed packet (the reference panics)"};
+                                 "alac: malformed packet (the reference panics)", "alac: packet outside the blob"};
     std::string s = "decode failed";
     const int c = ALACGPU_STATUS_CTX(st), g = ALACGPU_STATUS_STAGE(st), k = ALACGPU_STATUS_CODE(st);
     if (c > 0 && c < 5) s += std::string(": ") + ctx[c];
     if (g > 0) s += std::string(": ") + stage[g];
-    s += std::string(": ") + (k < 7 ? code[k] : "alac: unknown status");
+    s += std::string(": ") + (k < 8 ? code[k] : "alac: unknown status");
     return s;
 }
 

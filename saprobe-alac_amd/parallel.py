@@ -63,7 +63,7 @@ class ShardedDecoder:
             try:
                 lo, hi = shard_range(n, world, g)
                 sub = offsets[lo:hi + 1] - offsets[lo]
-                results[g] = self.decoders[g].decode_batch(blob[int(offsets[lo]):int(offsets[hi]) + 1], sub)
+                results[g] = self.decoders[g].decode_batch(blob[int(offsets[lo]):max(int(offsets[hi]), int(offsets[lo]) + 1)], sub)
             except Exception as e:  # noqa: BLE001
                 errors.append(e)
 

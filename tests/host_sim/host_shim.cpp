@@ -6,6 +6,7 @@
 #include <cstring>
 
 #ifdef SHIM_WITH_DECODER
+#include "../../saprobe-alac_amd/host/sharded_decoder.hpp"
 #include "../../saprobe-alac_amd/host/stream_decoder.hpp"
 #else
 #include "../../saprobe-alac_amd/host/mp4_demux.hpp"
@@ -58,5 +59,16 @@ long shim_read(void* d, uint8_t* p, size_t n) {
 long long shim_seek(void* d, long long ns) { return static_cast<alac::Decoder*>(d)->Seek(ns); }
 long long shim_duration(void* d) { return static_cast<alac::Decoder*>(d)->Duration(); }
 long long shim_position(void* d) { return static_cast<alac::Decoder*>(d)->Position(); }
+
+/* host/sharded_decoder.hpp: one handle + one host thread per entry of devices[] */
+long shim_sharded_decode(const alacgpu_config* cfg, const int* devices, size_t n_devices, const uint8_t* blob,
+                         const uint64_t* offsets, size_t n, uint8_t* out, size_t out_stride, uint32_t* frames,
+                         int32_t* status) {
+    SHIM_TRY({
+        alac::ShardedDecoder dec(*cfg, std::vector<int>(devices, devices + n_devices));
+        dec.DecodePackets(blob, offsets, n, out, out_stride, frames, status);
+    });
+    return 0;
+}
 #endif
 }

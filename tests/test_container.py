@@ -202,7 +202,7 @@ def _build_shim(with_decoder, pkg=None):
     host = os.path.join(_ROOT, "saprobe-alac_amd", "host")
     srcs = [os.path.join(d, "host_shim.cpp")] + [os.path.join(host, h) for h in os.listdir(host)]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, srcs[0]]
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-pthread", "-shared", "-o", so, srcs[0]]
         if with_decoder:
             libdir = os.path.dirname(pkg.lib_path())
             cmd += ["-DSHIM_WITH_DECODER", "-L" + libdir, "-lalacgpu", "-Wl,-rpath," + libdir]
