@@ -222,13 +222,20 @@ def main():
                               "best of 3; bytes = packets up + PCM down",
                       "pageable": run_host(False), "pinned": run_host(True)}
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_final", "traffic.json")
-    if (depth, ch, FL, P) == (16, 2, 4096, 65536) and os.path.exists(tpath):
+    # HBM bytes per launch from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md): they cannot run
+    # inside the bench, so the committed figure is used — but only if it was taken from THIS source of the kernels
+    traffic, traffic_src = None, None
+    for tdir in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r")), reverse=True):
+        tpath = os.path.join(ROOT, "profiles", tdir, "traffic.json")
+        if not os.path.exists(tpath):
+            continue
         try:
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]  # PMC passes cannot run inside the bench
+            t = json.load(open(tpath))
+            if t.get("csrc_sha256") == pkg.csrc_sha256() and t.get("workload") == [depth, ch, FL, P, args.profile]:
+                traffic, traffic_src = t["traffic_bytes_per_launch"], "profiles/%s/traffic.json" % tdir
         except Exception:
-            traffic = None
+            pass
+        break
 
     if rank == 0:
         value = samples * world * args.steps / elapsed / 1e6
@@ -246,8 +253,9 @@ def main():
                        "sharding": "independent packet ranges, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None,
-                         "traffic": traffic, "traffic_source": "profiles/r01_final/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)" if traffic else None,
-                         "kernel": "alac_decode", "kernel_ms": round(kernel_ms, 4),
+                         "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload and this source)") if traffic else None,
+                         "kernel": "alac_decode" if ch <= 2 else "alac_scan + alac_chan_predict + alac_interleave",
+                         "kernel_ms": round(kernel_ms, 4), "kernel_ms_is": "HIP events on the handle's stream around all kernels of one decode (sort pre-pass included)",
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu, "bit_exact": bit_exact, "gen_seconds": round(gen_s, 2), "host_entry": host_entry,
         }

@@ -172,6 +172,17 @@ def build(force=False):
     return so
 
 
+def csrc_sha256():
+    """Fingerprint of the kernel sources (csrc/*.hip, *.h, *.inc): profiles/*/traffic.json is stamped with it."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(_CSRC)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(_CSRC, f), "rb").read())
+    return h.hexdigest()
+
+
 _EXPORTS = {
     "alacgpu_create": (ctypes.c_int, [ctypes.POINTER(PacketConfig), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "alacgpu_destroy": (None, [ctypes.c_void_p]),

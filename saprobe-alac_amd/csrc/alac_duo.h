@@ -243,6 +243,18 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     int32_t upre[UN];
     uint64_t spre[UN];
     uint32_t pre_row = 0xffffffffu; /* first frame of the group upre / spre hold */
+    /* 3-byte pairs (24-bit with one shift byte per sample, 20-bit): four frames are exactly six dwords, at the same
+     * byte positions in every group, and the eight shift bytes of four frames are eight consecutive stream bytes. The
+     * writer then works per group: one 12-byte fetch for the shift bytes (instead of four 8-byte windows), byte picks
+     * instead of 64-bit shifts, three byte permutes per two frames instead of the generic packer's selects
+     * (BASELINE config c). All live lanes must agree on the shift width (a wave of 24-bit packets with bytesShifted 2
+     * among them takes the generic writer). */
+    constexpr bool PK3 = CPE && LAST && !F16 && !RAW && !EMIT_A && UN == 4u;
+    const bool sb8 = PK3 && !wv.any(ns != 0u && sb != 8u);
+    const bool sb0 = PK3 && !wv.any(ns != 0u && sb != 0u);
+    const bool pk3 = PK3 && bps == 3u && (sb8 || sb0);
+    const uint32_t sh_byte = shift_pos >> 3, sh_bit = shift_pos & 7u;
+    uint32_t gpre0 = 0, gpre1 = 0, gpre2 = 0;
     const uint32_t sstep_b = (CPE ? 2u : 1u) * sb;
     const uint32_t steady_end = (n_it / CH) * CH; /* whole chunks end here */
     auto prefetch_group = [&](uint32_t row0) {
@@ -252,8 +264,9 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             upre[j] = 0;
             spre[j] = 0;
             if (CPE) upre[j] = *wv.u_row(row0 + j);
-            if (merge_any) spre[j] = bits.window_raw(shift_pos + (row0 + j) * sstep_b);
+            if (merge_any && !pk3) spre[j] = bits.window_raw(shift_pos + (row0 + j) * sstep_b);
         }
+        if (PK3 && pk3 && sb8) bits.load12(sh_byte + 2u * row0, gpre0, gpre1, gpre2);
     };
     /* B: samples of chunk c (UnpcBlock, predictor.go:45-684): out[0] = residual, warm-up up to na (:53-79),
      * copy (0) / delta (31) modes, then the adaptive taps */
@@ -280,7 +293,55 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
                         sv[j] = AHEAD ? spre[j] : 0ull;
                         if (HBM_IN && !AHEAD && CPE) uv[j] = *wv.u_row(row0 + j);
                     }
+                    const uint32_t g0 = gpre0, g1 = gpre1, g2 = gpre2;
                     if (AHEAD && row0 + 2u * UN <= steady_end) prefetch_group(row0 + UN);
+                    if (PK3 && pk3) {
+                        /* the eight shift bytes of the group: stream bits sh_bit .. sh_bit + 64 of the 12 bytes fetched */
+                        const uint32_t w0 = (uint32_t)(((((uint64_t)g0) << 32) | g1) << sh_bit >> 32);
+                        const uint32_t w1 = (uint32_t)(((((uint64_t)g1) << 32) | g2) << sh_bit >> 32);
+                        uint32_t lq[4], rq[4];
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; ++j) {
+                            const int32_t vv = predict(dv[j], wrap);
+#pragma unroll
+                            for (int t = NR; t >= 1; --t) hb[t] = hb[t - 1];
+                            hb[0] = (uint32_t)vv ^ BIAS;
+                            /* matrix.go:40-41 / :50-51, as in emit() */
+                            const int32_t mv = NARROW ? ALAC_MUL24(mix_res, vv) : (int32_t)((uint32_t)mix_res * (uint32_t)vv);
+                            int32_t l = uv[j] + (int32_t)((uint32_t)vv & nzm) - (mv >> mix_sh);
+                            int32_t r = (int32_t)((((uint32_t)(l - vv)) & nzm) | ((uint32_t)vv & ~nzm));
+                            if (sb8) { /* matrix.go:129-132 */
+                                const uint32_t w = j < 2u ? w0 : w1;
+                                const uint32_t sl = (j & 1u) ? (w >> 8) & 0xffu : w >> 24;
+                                const uint32_t sr = (j & 1u) ? w & 0xffu : (w >> 16) & 0xffu;
+                                l = (int32_t)(((uint32_t)l << 8) | sl);
+                                r = (int32_t)(((uint32_t)r << 8) | sr);
+                            } else if (cfg.bit_depth == 20) { /* matrix.go:77-78 */
+                                l = (int32_t)((uint32_t)l << 4);
+                                r = (int32_t)((uint32_t)r << 4);
+                            }
+                            lq[j] = (uint32_t)l;
+                            rq[j] = (uint32_t)r;
+                        }
+                        /* L0 L0 L0 R0 | R0 R0 L1 L1 | L1 R1 R1 R1, twice */
+                        const uint32_t d0 = (lq[0] & 0xffffffu) | (rq[0] << 24);
+                        const uint32_t d1 = ((rq[0] >> 8) & 0xffffu) | (lq[1] << 16);
+                        const uint32_t d2 = ((lq[1] >> 16) & 0xffu) | (rq[1] << 8);
+                        const uint32_t d3 = (lq[2] & 0xffffffu) | (rq[2] << 24);
+                        const uint32_t d4 = ((rq[2] >> 8) & 0xffffu) | (lq[3] << 16);
+                        const uint32_t d5 = ((lq[3] >> 16) & 0xffu) | (rq[3] << 8);
+                        /* a lane whose frames end inside the group (a partial frame) keeps the whole dwords of its
+                         * 6, 12 or 18 bytes; an odd count leaves two bytes for st_tail, as the generic packer would */
+                        const uint32_t nv = umin(ALAC_SUBSAT(ns, row0), 4u);
+                        const uint32_t nby = nv * 6u;
+                        wv.st_push6_n(d0, d1, d2, d3, d4, d5, nby >> 2);
+                        if (nby & 2u) {
+                            pk_acc = (nv == 1u ? d1 : d4) & 0xffffu;
+                            pk_n = 2u;
+                        }
+                        wv.st_step();
+                        continue;
+                    }
 #pragma unroll
                     for (uint32_t j = 0; j < UN; ++j)
                         put(buf, g + j, c * CH + g + j, predict(dv[j], wrap), uv[j], sv[j]);

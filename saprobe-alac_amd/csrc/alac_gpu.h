@@ -186,6 +186,30 @@ struct GpuWave {
         s_rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
         wcnt += on ? 1u : 0u;
     }
+    /* six dwords at once (four 24-bit stereo frames): straight on from the lane's position; the one group in ten
+     * that crosses the end of the ring (the same one for every lane that is still going) wraps dword by dword */
+    /* (all six are stored; the lane's position moves on by `count`) */
+    ALAC_DEV void st_push6_n(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t d4, uint32_t d5, uint32_t count) {
+        const uint32_t pos = wcnt & (kRing - 1u);
+        uint32_t* row = s_rows + lane * kRowStride;
+        if (pos <= kRing - 6u) {
+            uint32_t* r = row + pos;
+            r[0] = d0;
+            r[1] = d1;
+            r[2] = d2;
+            r[3] = d3;
+            r[4] = d4;
+            r[5] = d5;
+        } else {
+            row[pos] = d0;
+            row[(pos + 1u) & (kRing - 1u)] = d1;
+            row[(pos + 2u) & (kRing - 1u)] = d2;
+            row[(pos + 3u) & (kRing - 1u)] = d3;
+            row[(pos + 4u) & (kRing - 1u)] = d4;
+            row[(pos + 5u) & (kRing - 1u)] = d5;
+        }
+        wcnt += count; /* the lane keeps the first `count` of them (a partial frame ends inside the group) */
+    }
     /* bytes of the last, incomplete dword of the stream (after every dword pushed so far) */
     ALAC_DEV void st_tail(uint64_t acc, uint32_t nbytes) {
         for (uint32_t b = 0; b < nbytes; ++b) my_out[(size_t)wcnt * 4u + b] = (uint8_t)(acc >> (8u * b));

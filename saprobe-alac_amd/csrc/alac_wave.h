@@ -108,12 +108,23 @@ struct BitsT {
         }
         return __builtin_bswap64(raw) << (pos & 7u);
     }
-    /* the same without the end handling, for windows the caller knows to lie wholly inside the packet (the shift
-     * values of a regular packet: classify_regular keeps 8 bytes of entropy stream behind them) */
+    /* the same without the end handling, for windows that lie wholly inside the packet when the lane is still
+     * decoding (the shift values of a regular packet: classify_regular keeps 8 bytes of entropy stream behind them).
+     * A lane that has run out of frames keeps being asked (lock step): its offset is held inside its packet, what it
+     * reads is not used. Needs size >= 8. */
     ALAC_DEV uint64_t window_raw(uint32_t pos) const {
         uint64_t raw;
-        __builtin_memcpy(&raw, p + (pos >> 3), 8);
+        __builtin_memcpy(&raw, p + umin(pos >> 3, size - 8u), 8);
         return __builtin_bswap64(raw) << (pos & 7u);
+    }
+    /* 12 bytes from byte offset `off` (same rule: held inside the packet; needs size >= 12), as three big-endian
+     * dwords: bits [8*off, 8*off + 96) of the stream */
+    ALAC_DEV void load12(uint32_t off, uint32_t& a, uint32_t& b, uint32_t& c) const {
+        uint32_t raw[3];
+        __builtin_memcpy(raw, p + umin(off, size - 12u), 12);
+        a = __builtin_bswap32(raw[0]);
+        b = __builtin_bswap32(raw[1]);
+        c = __builtin_bswap32(raw[2]);
     }
     /* n bits (0..32) at pos: BitBuffer.Read / ReadSmall / ReadOne all reduce to this (bitbuffer.go:55-96) */
     ALAC_DEV uint32_t get(uint32_t pos, uint32_t n) const {

@@ -15,6 +15,8 @@
 #include <vector>
 
 #define ALAC_DEV inline
+/* as narrow as the GPU's v_mul_i32_i24: a use on operands that do not fit 24 bits must show up here too */
+#define ALAC_MUL24(a, b) ((int32_t)((uint32_t)(((int32_t)((uint32_t)(a) << 8)) >> 8) * (uint32_t)(((int32_t)((uint32_t)(b) << 8)) >> 8)))
 #include "../../saprobe-alac_amd/csrc/alac_wave.h"
 #include "../../saprobe-alac_amd/csrc/alac_regular.h"
 #include "../../saprobe-alac_amd/csrc/alac_duo.h"
@@ -40,6 +42,10 @@ struct HostWave {
     }
     void st_push_if(uint32_t v, bool on) {
         if (on) st_push(v);
+    }
+    void st_push6_n(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t d4, uint32_t d5, uint32_t count) {
+        const uint32_t d[6] = {d0, d1, d2, d3, d4, d5};
+        for (uint32_t k = 0; k < count; ++k) st_push(d[k]);
     }
     void st_tail(uint64_t acc, uint32_t nbytes) {
         for (uint32_t b = 0; b < nbytes; ++b) st_out[4u * (size_t)st_cnt + b] = (uint8_t)(acc >> (8u * b));

@@ -279,3 +279,34 @@ def test_wave_pair_chunk_tails_and_full_waves(pkg, oracle, synth, helpers, gpu_d
                 ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=8)
                 got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
                 helpers.assert_same_decode(cfg, ref, got, bpf, "ppw %s profile %d" % (ppw, prof))
+
+
+@pytest.mark.parametrize("ch,n", [(2, 65536), (8, 16384)])
+def test_baseline_configs_c_and_d_at_full_size(pkg, synth, oracle, gpu_decoder_factory, ch, n):
+    """BASELINE config c (65 536 x 24-bit stereo with shift bytes) and d (16 384 x 24-bit 7.1) at their full batch
+    sizes through the device-resident entry: several rounds of workgroups per CU, the sort with every key present.
+    Checked by the size-independent property decode(encode(pcm)) == pcm (tests/conformance_test.go:282-291), frame
+    counts and status words; the oracle decodes a slice."""
+    import torch
+    cfg = oracle.make_config(4096, 24, ch)
+    b = synth.gen_batch(cfg, n, threads=16)
+    dev = torch.device("cuda:0")
+    stride = 4096 * ch * 3
+    d_blob = torch.from_numpy(b.blob).to(dev)
+    d_off = torch.from_numpy(b.offsets.astype(np.int64)).to(dev)
+    d_sz = torch.from_numpy(b.sizes.astype(np.int32)).to(dev)
+    d_out = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    d_fr = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with gpu_decoder_factory(cfg) as dec:
+        dec.decode_batch_device(d_blob.data_ptr(), d_blob.numel(), d_off.data_ptr(), d_sz.data_ptr(), n, d_out.data_ptr(),
+                                stride, d_fr.data_ptr(), d_st.data_ptr(), sync=True)
+    assert int(d_st.abs().sum()) == 0
+    assert np.array_equal(d_fr.cpu().numpy().astype(np.uint32), b.frames)
+    for lo in range(0, n, 4096):  # nothing is written behind a partial frame either: whole slots compare equal
+        exp = torch.from_numpy(b.pcm[lo:lo + 4096]).to(dev)
+        assert torch.equal(d_out[lo:lo + 4096], exp), lo
+        del exp
+    ref = oracle.decode_batch(cfg, b.blob, b.offsets[:128], b.sizes[:128], threads=8)
+    assert np.array_equal(ref[0], d_out[:128].cpu().numpy())

@@ -167,3 +167,14 @@ def test_unsupported_configs(oracle):
     assert not oracle.lib().alac_oracle_create(__import__("ctypes").byref(oracle.make_config(64, 13, 2)))
     assert not oracle.lib().alac_oracle_create(__import__("ctypes").byref(oracle.make_config(64, 16, 0)))
     assert not oracle.lib().alac_oracle_create(__import__("ctypes").byref(oracle.make_config(64, 16, 9)))
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("depth,ch", [(32, 1), (32, 2), (32, 8), (24, 8), (20, 3)])
+def test_packet_generator_terminates_on_the_stress_profile(oracle, synth, depth, ch):
+    """Regression: the generator's bit writer once overflowed its slot on 32-bit STRESS packets and the byte-align
+    loop behind it never ended (round 1, `bw_put`). The fuzz harnesses depend on the generator returning."""
+    cfg = oracle.make_config(4096, depth, ch)
+    for seed in (0x5A9B0BE, 1, 0xFFFFFFFF):
+        b = synth.gen_batch(cfg, 96, profile=synth.PROFILE_STRESS, base_seed=seed, threads=4)
+        assert b.n == 96 and int(b.sizes.min()) > 0
