@@ -122,6 +122,8 @@ class PacketConfig(ctypes.Structure):
     mb = property(lambda s: s.MB)
     kb = property(lambda s: s.KB)
     max_run = property(lambda s: s.MaxRun)
+    max_frame_bytes = property(lambda s: s.MaxFrameBytes)
+    avg_bit_rate = property(lambda s: s.AvgBitRate)
     sample_rate = property(lambda s: s.SampleRate)
 
 

@@ -239,6 +239,11 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     constexpr uint32_t UN = (NARROW && (((F16 || !LAST || RAW || EMIT_A) && NR <= ALAC_DUO_UN8_MAX) ||
                                         NR <= ALAC_DUO_UN8_WIDE_MAX)) ? 8u : 4u;
     constexpr bool HBM_IN = LAST && !RAW && !EMIT_A; /* the writer runs here and reads the U tile / shift bytes */
+    /* role B fed from memory (split pipeline's predictor pass: W::kResMem): the residuals of a group are requested one
+     * group ahead, like the U samples of the wide writers */
+    constexpr bool RMEM = W::kResMem && ROLE == ROLE_B;
+    int32_t dpre[UN];
+    uint32_t dpre_row = 0xffffffffu;
     constexpr bool AHEAD = HBM_IN && !F16;
     int32_t upre[UN];
     uint64_t spre[UN];
@@ -286,15 +291,24 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
                     int32_t dv[UN], uv[UN];
                     uint64_t sv[UN];
                     if (AHEAD && pre_row != row0) prefetch_group(row0); /* first steady group: nothing was ahead */
+                    if (RMEM && dpre_row != row0) {
+#pragma unroll
+                        for (uint32_t j = 0; j < UN; ++j) dpre[j] = wv.rq_read(buf, g + j);
+                    }
 #pragma unroll
                     for (uint32_t j = 0; j < UN; ++j) {
-                        dv[j] = wv.rq_read(buf, g + j);
+                        dv[j] = RMEM ? dpre[j] : wv.rq_read(buf, g + j);
                         uv[j] = AHEAD ? upre[j] : 0;
                         sv[j] = AHEAD ? spre[j] : 0ull;
                         if (HBM_IN && !AHEAD && CPE) uv[j] = *wv.u_row(row0 + j);
                     }
                     const uint32_t g0 = gpre0, g1 = gpre1, g2 = gpre2;
                     if (AHEAD && row0 + 2u * UN <= steady_end) prefetch_group(row0 + UN);
+                    if (RMEM && row0 + 2u * UN <= steady_end) { /* rq_read indexes from the chunk's first step */
+                        dpre_row = row0 + UN;
+#pragma unroll
+                        for (uint32_t j = 0; j < UN; ++j) dpre[j] = wv.rq_read(buf, g + UN + j);
+                    }
                     if (PK3 && pk3) {
                         /* the eight shift bytes of the group: stream bits sh_bit .. sh_bit + 64 of the 12 bytes fetched */
                         const uint32_t w0 = (uint32_t)(((((uint64_t)g0) << 32) | g1) << sh_bit >> 32);

@@ -153,6 +153,7 @@ __host__ __device__ inline size_t u_tile_cells(uint32_t frame_length) { return (
 
 /* ---- gfx950 wave policy for alac::decode_wave --------------------------------------------------------- */
 struct GpuWave {
+    static constexpr bool kResMem = false; /* residuals come through the LDS queue */
     int32_t* u_tile;           /* HBM: this lane's column of the wave's U hand-off tile */
     int32_t* g_tile;           /* HBM: this lane's column of the wave's fall-back tile */
     uint8_t* my_out;
@@ -273,6 +274,7 @@ struct GpuWave {
  * task's row, scan_channel): role B of alac_duo.h with the residual "queue" read straight from the row — no entropy
  * wave, no barrier. duo_sync() is called once per chunk iteration and moves the window on. */
 struct GpuWaveMem : GpuWave {
+    static constexpr bool kResMem = true;
     const int32_t* res; /* this lane's row: residuals in, samples out (the writer runs 32+ samples behind the reads) */
     uint32_t it, chunk0;
     ALAC_DEV int32_t rq_read(uint32_t, uint32_t j) const { return res[chunk0 + j]; }

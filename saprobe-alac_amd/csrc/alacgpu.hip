@@ -202,6 +202,7 @@ struct alacgpu_decoder {
     DevBuf cd, pd, plan2, keys2, perm2, rows;                /* split pipeline (more than two channels) */
     Slot slots[kSlots];                                      /* host-entry staging */
     CopyPool* pool;
+    uint32_t il_threads;                                     /* alac_interleave block size (64, 128 or 256) */
     size_t chunk_bytes;                                      /* host entry: target bytes (in + out) per chunk */
 };
 
@@ -295,7 +296,10 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
     if (dec->cfg.kb != 0) {
         /* irregular packets were only scanned by alac_scan (status, frames, channel descriptors) */
         const uint64_t rs = row_stride_of(dec->cfg.frame_length);
-        const uint32_t bpp = (dec->cfg.frame_length + 255u) / 256u;
+        /* frames per interleave block: one wavefront's worth keeps more blocks in flight per CU (the kernel waits on
+         * memory, not on arithmetic) */
+        const uint32_t il_threads = dec->il_threads;
+        const uint32_t bpp = (dec->cfg.frame_length + il_threads - 1u) / il_threads;
         if (dec->cfg.num_channels > 2) {
             /* split pipeline: one lane per channel, sorted by predictor order */
             Plan* plan2 = (Plan*)dec->plan2.p;
@@ -314,8 +318,8 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
                                (const alac::ChanDesc*)dec->cd.p, (int32_t*)dec->rows.p, rs, ppw2);
         }
         /* PCM of the split packets (with one or two channels: of the escape-only packets) */
-        const uint32_t ib = (uint32_t)std::min<uint64_t>((uint64_t)n * bpp, 8192);
-        hipLaunchKernelGGL(alac_interleave, dim3(ib), dim3(256), 0, dec->stream, c, d_blob, blob_bytes, d_offsets, sz,
+        const uint32_t ib = (uint32_t)std::min<uint64_t>((uint64_t)n * bpp, 8192u * (256u / il_threads));
+        hipLaunchKernelGGL(alac_interleave, dim3(ib), dim3(il_threads), 32u * il_threads, dec->stream, c, d_blob, blob_bytes, d_offsets, sz,
                            (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::ChanDesc*)dec->cd.p,
                            (const alac::PktDesc*)dec->pd.p, (const int32_t*)dec->rows.p, rs, d_out, (uint64_t)out_stride, bpp);
         hipLaunchKernelGGL(alac_legacy, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, blob_bytes,
@@ -373,6 +377,11 @@ int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out)
                               (uint32_t)bps, 0u};
     d->launches = 0;
     d->pool = nullptr;
+    d->il_threads = 64;
+    if (const char* e = getenv("ALACGPU_IL_THREADS")) {
+        const int v = atoi(e);
+        if (v == 64 || v == 128 || v == 256) d->il_threads = (uint32_t)v;
+    }
     d->chunk_bytes = (size_t)192 << 20;
     if (const char* e = getenv("ALACGPU_CHUNK_MB")) {
         const long v = atol(e);

@@ -7,7 +7,7 @@ namespace alack {
 
 /* Split pipeline, predictor pass: one wavefront per 64 channel tasks with the same key; the residuals are in the
  * task's row (left there by alac_scan), the samples replace them. */
-__global__ void __launch_bounds__(kWave, 2)
+__global__ void __launch_bounds__(kWave, 3)
 alac_chan_predict(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
                   const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
                   const alac::ChanDesc* __restrict__ cd, int32_t* __restrict__ rows, uint64_t row_stride, uint32_t ppw) {
@@ -55,14 +55,14 @@ alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blo
                 const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
                 const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd, const int32_t* __restrict__ rows,
                 uint64_t row_stride, uint8_t* __restrict__ out, uint64_t out_stride, uint32_t blocks_per_pkt) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_slice[256 * 32];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_slice[]; /* blockDim.x frames of <= 32 bytes (launch: 32 * blockDim.x) */
     const uint32_t n_scan = plan->count[kKeyScan];
     const uint32_t first = plan->pkt_start[kKeyScan];
     const uint64_t items = (uint64_t)n_scan * blocks_per_pkt;
     const uint32_t fb = cfg.num_channels * cfg.bps;
     for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
         const uint32_t pkt = perm[first + (uint32_t)(it / blocks_per_pkt)];
-        const alac::PktDesc q = pd[pkt];
+        const alac::PktDesc& q = pd[pkt]; /* read in place: a copy indexed by slot would live in scratch memory */
         if (q.status != 0 || q.route != alac::ROUTE_SPLIT) continue; /* block-uniform */
         const uint32_t f0 = (uint32_t)(it % blocks_per_pkt) * blockDim.x;
         if (f0 >= q.frames) continue;
@@ -91,14 +91,14 @@ alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blo
 #undef ALAC_IL_CASE
         }
         __syncthreads();
-        uint8_t* dst = out + (size_t)pkt * out_stride + (size_t)f0 * fb; /* f0 * fb is a multiple of 256 */
+        uint8_t* dst = out + (size_t)pkt * out_stride + (size_t)f0 * fb; /* f0 is a multiple of 64: 16-byte aligned */
         const uint32_t total = nf * fb;
         if (cfg.aligned16) {
-            for (uint32_t k = threadIdx.x * 16u; k + 16u <= total; k += 256u * 16u)
+            for (uint32_t k = threadIdx.x * 16u; k + 16u <= total; k += blockDim.x * 16u)
                 *reinterpret_cast<uint4*>(dst + k) = *reinterpret_cast<const uint4*>(s_slice + k);
-            for (uint32_t k = (total & ~15u) + threadIdx.x; k < total; k += 256u) dst[k] = s_slice[k];
+            for (uint32_t k = (total & ~15u) + threadIdx.x; k < total; k += blockDim.x) dst[k] = s_slice[k];
         } else {
-            for (uint32_t k = threadIdx.x; k < total; k += 256u) dst[k] = s_slice[k];
+            for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) dst[k] = s_slice[k];
         }
         __syncthreads();
     }

@@ -26,6 +26,7 @@ namespace {
 
 /* one-lane wave: collectives are identities, the stager writes straight to the PCM slot */
 struct HostWave {
+    static constexpr bool kResMem = false;
     std::vector<int32_t> u_tile, g_tile;
     uint8_t* st_out = nullptr;
     uint32_t st_cnt = 0;
@@ -74,6 +75,7 @@ struct HostWave {
  * writes a sample the moment it is pushed; the reads run ahead of the writes (sample i is written after residual i
  * was read), as on the GPU. */
 struct HostWaveMem : HostWave {
+    static constexpr bool kResMem = true;
     const int32_t* res = nullptr;
     uint32_t it = 0, chunk0 = 0;
     explicit HostWaveMem(uint32_t frame_length) : HostWave(frame_length) {}
