@@ -7,8 +7,10 @@
  * the wave stage PCM through LDS and write it back as whole 128-B lines (W::st_*), and confines
  * divergence to rare paths (escape codes, zero-run starts, escape elements). Control flow is
  * wave-uniform (loop bounds are wave maxima, bodies are predicated per lane) because the LDS flush is a
- * collective. Packets are pre-sorted by predictor-order class so the predictor is compiled for NA
- * register taps (4 / 6 / 8 / 16) and a wave never pays for taps it does not have.
+ * collective. This file holds the whole-packet form (decode_wave): any depth, any element mix, orders 0..31 on NA
+ * register taps plus a per-lane fall-back tile. Since round 1's wave pair it runs only as the SCAN pass of irregular
+ * packets (entropy only: status, frame count, channel descriptors, residual rows) and as the decoder of the few
+ * packets the scan routes ROUTE_LEGACY; regular packets, sorted by (numU, numV, width), take alac_duo.h.
  *
  * Nothing here is a port: the reference decodes one packet at a time with whole-block passes
  * (DynDecomp over the block, then UnpcBlock, then Write*); this fuses them per sample and keeps the
@@ -18,8 +20,8 @@
  * (mycophonic/saprobe-alac) for every input, including Go's shift/wrap semantics. Reference lines are
  * cited at each step (paths relative to the reference tree).
  *
- * The file is plain C++ templated on a wave policy W: alacgpu.hip instantiates it with the gfx950
- * policy (LDS stager, ballots, DPP reductions); tests/host_sim instantiates it with a one-lane policy
+ * The file is plain C++ templated on a wave policy W: the k_*.hip units instantiate it with the gfx950
+ * policy of alac_gpu.h (LDS stager, ballots, DPP reductions); tests/host_sim instantiates it with a one-lane policy
  * and g++ to check the LOGIC against the oracle where no GPU exists. It is not a CPU decode path of the
  * product: libalacgpu.so contains no host decoder.
  */
