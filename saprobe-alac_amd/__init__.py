@@ -203,6 +203,8 @@ _EXPORTS = {
     "alacgpu_timing_reset": (ctypes.c_int, [ctypes.c_void_p]),
     "alacgpu_kernel_times": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                             ctypes.POINTER(ctypes.c_size_t)]),
+    "alacgpu_pair_placement": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                              ctypes.POINTER(ctypes.c_size_t)]),
     "alacgpu_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
     "alacgpu_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
     "alacgpu_last_error": (ctypes.c_char_p, []),
@@ -363,6 +365,15 @@ class PacketDecoder:
         got = ctypes.c_size_t()
         _check(self._lib.alacgpu_kernel_times(self._h, ms.ctypes.data, max_n, ctypes.byref(got)))
         return ms[:got.value].copy()
+
+    def pair_placement(self, max_slots=1 << 16):
+        """Diagnostics of the last device decode (include/alacgpu.h: alacgpu_pair_placement): an (n_slots, 4) uint32
+        array, one row per wave slot of the launch plan — [tag, clock at start, clock at end, 0]; all zero for slots
+        that no gated wave pair decoded."""
+        raw = np.zeros((max_slots, 4), dtype=np.uint32)
+        got = ctypes.c_size_t()
+        _check(self._lib.alacgpu_pair_placement(self._h, raw.ctypes.data, raw.size, ctypes.byref(got)))
+        return raw[:got.value].copy()
 
     def synchronize(self):
         _check(self._lib.alacgpu_synchronize(self._h))

@@ -64,7 +64,8 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     constexpr bool LAST = OUT == OUT_STEREO || OUT == OUT_MONO || RAW; /* B stages what it reconstructs */
     constexpr bool CPE = OUT == OUT_STEREO;
     constexpr bool GEN = NA == 0;
-    constexpr int NR = GEN ? 16 : NA;
+    /* GEN only ever serves orders 0 (copy) and 31 (delta): every order with taps has its own instantiation */
+    constexpr int NR = GEN ? 1 : NA;
     constexpr bool WRAP = !(NA == 4 || NA == 5 || NA == 6 || NA == 8); /* predictor.go:81-93 */
     constexpr uint32_t BIAS = 0x80000000u;
     /* EA: the PCM writer runs in wave A (long predictors: B is the longer of the two). Samples then go B -> A
@@ -479,7 +480,7 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits,
  * returns the status word and sets *frames_out. The caller playing role B passes the same arguments; its return
  * value and *frames_out mean nothing.
  */
-template <class W, int ROLE, int WIDE_SEL = -1>
+template <class W, int ROLE, int WIDE_SEL = -1, int DEPTH_SEL = 0>
 ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
                                     uint32_t avail, uint8_t* out, uint32_t* frames_out) {
     constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
@@ -551,10 +552,11 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
         if (DO_A) s.rd.start(wv, (live && s.err == 0) ? s.pos : 0u);
         if constexpr (WIDE_SEL != 0) if (wide)
             duo_phase_na<W, OUT_STEREO, ROLE, false, false>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+        /* DEPTH_SEL 16 / 24 / 32: the caller's configuration has that sample width (24 stands for both 3-byte depths) */
         if constexpr (WIDE_SEL != 1) if (!wide) {
-            if (cfg.bit_depth == 16)
+            if constexpr (DEPTH_SEL == 0 || DEPTH_SEL == 16) if (cfg.bit_depth == 16)
                 duo_phase_na<W, OUT_STEREO, ROLE, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
-            else
+            if constexpr (DEPTH_SEL != 16) if (cfg.bit_depth != 16)
                 duo_phase_na<W, OUT_STEREO, ROLE, false>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
         }
         if (err_u == 0 && s.err != 0) err_chan = 1;

@@ -115,10 +115,22 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kWave = 64;
 constexpr uint32_t kTimingSlots = 64;
-constexpr uint32_t kRowStride = 65; /* dwords per lane row in LDS: odd stride = conflict-free column access */
-constexpr uint32_t kRing = 64;      /* dwords of PCM a lane row holds (two 128-B chunks) */
+/* LDS footprint of a wave pair, set per translation unit. ALAC_LDS_ROWS: dwords of PCM a lane row holds, flushed half
+ * a row at a time (64: whole 128-byte lines per packet; 32: 64-byte pieces, the two halves of a line follow each other
+ * through L2). ALAC_LDS_RING: dwords of bitstream ring per lane (32 or 16). 64/32 = 34.5 KB per workgroup = four pairs
+ * per CU; 32/32 = 26.1 KB = six; 32/16 = 21.9 KB = seven. */
+#ifndef ALAC_LDS_ROWS
+#define ALAC_LDS_ROWS 64
+#endif
+#ifndef ALAC_LDS_RING
+#define ALAC_LDS_RING 32
+#endif
+constexpr uint32_t kRing = ALAC_LDS_ROWS;                   /* dwords of PCM a lane row holds (two flush chunks) */
+constexpr uint32_t kFlush = kRing / 2;                      /* dwords per lane and flush */
+constexpr uint32_t kRowStride = kRing + 1;                  /* odd stride = conflict-free column access */
 constexpr uint32_t kFallbackSlots = 64;
-constexpr uint32_t kRingStride = 36; /* 32 ring dwords + 4: rows stay 16-byte aligned, lanes spread over banks */
+constexpr uint32_t kRingDw = ALAC_LDS_RING;                 /* bitstream ring, dwords per lane */
+constexpr uint32_t kRingStride = kRingDw + 4;               /* rows stay 16-byte aligned, lanes spread over banks */
 
 /* device-side launch plan, rebuilt by every decode */
 /* sort keys: 0..2047 regular packets (numU*32 + numV + KEY_WIDE, alac_regular.h); 2048 / 2049 irregular packets
@@ -135,7 +147,13 @@ struct Plan {
     uint32_t list_key[kKeys];
     uint32_t list_wave0[kKeys]; /* first block id */
     uint32_t total_waves;
-    uint32_t irr_waves; /* waves of the irregular keys (>= KEY_IRREGULAR): they come first */
+    uint32_t irr_waves;  /* waves of the irregular keys (>= KEY_IRREGULAR): they come first */
+    uint32_t wide_waves; /* then those of the wide keys (KEY_WIDE..), then the narrow ones */
+    /* the pair kernels (k_decode_body.inc; [0] narrow keys, [1] wide): workgroups admitted per CU so far and the
+     * next item of the queue. Zeroed with the rest of the plan before every decode. */
+    uint32_t gate[2][512];
+    uint32_t balance[2][512]; /* per SIMD of the CU, a byte each: entropy waves - predictor waves placed there */
+    uint32_t queue[2];
 };
 
 /* LDS of the decode kernel (one wave per workgroup). Referenced by name, never through a generic pointer, so
@@ -154,6 +172,7 @@ __host__ __device__ inline size_t u_tile_cells(uint32_t frame_length) { return (
 /* ---- gfx950 wave policy for alac::decode_wave --------------------------------------------------------- */
 struct GpuWave {
     static constexpr bool kResMem = false; /* residuals come through the LDS queue */
+    static constexpr uint32_t kRingDw = alack::kRingDw;
     int32_t* u_tile;           /* HBM: this lane's column of the wave's U hand-off tile */
     int32_t* g_tile;           /* HBM: this lane's column of the wave's fall-back tile */
     uint8_t* my_out;
@@ -215,21 +234,23 @@ struct GpuWave {
     ALAC_DEV void st_tail(uint64_t acc, uint32_t nbytes) {
         for (uint32_t b = 0; b < nbytes; ++b) my_out[(size_t)wcnt * 4u + b] = (uint8_t)(acc >> (8u * b));
     }
-    /* Collective. Rows that just completed a 32-dword chunk are written out as 128-B lines: store
-     * instruction k covers packets 8k..8k+7, eight lanes x 16 B per packet. Lock step makes `flushed`
-     * identical in all full lanes. */
+    /* Collective. Rows that just completed a kFlush-dword chunk are written out: kFlush / 4 lanes x 16 B per packet
+     * (whole 128-B lines with kFlush = 32, halves with 16), 64 / (kFlush / 4) packets per store instruction. Lock step
+     * makes `flushed` identical in all full lanes. */
     ALAC_DEV void st_step() {
-        const bool full = (wcnt - flushed) >= 32u;
+        constexpr uint32_t LPP = kFlush / 4u;      /* lanes per packet */
+        constexpr uint32_t PPI = kWave / LPP;      /* packets per store instruction */
+        const bool full = (wcnt - flushed) >= kFlush;
         const unsigned long long mask = __ballot(full);
         if (mask == 0ull) return;
         __builtin_amdgcn_wave_barrier();
         const int first = __ffsll((long long)mask) - 1;
         const uint32_t fl = (uint32_t)__shfl((int)flushed, first, 64);
         const uint32_t col0 = fl & (kRing - 1u);
-        const uint32_t piece = lane & 7u;
-        const uint32_t groups = (ppw + 7u) >> 3;
+        const uint32_t piece = lane & (LPP - 1u);
+        const uint32_t groups = (ppw + PPI - 1u) / PPI;
         for (uint32_t k = 0; k < groups; ++k) {
-            const uint32_t q = 8u * k + (lane >> 3);
+            const uint32_t q = PPI * k + lane / LPP;
             if ((mask >> q) & 1ull) {
                 const uint32_t* r = s_rows + q * kRowStride + col0 + piece * 4u;
                 const uint4 v = make_uint4(r[0], r[1], r[2], r[3]);
@@ -239,7 +260,7 @@ struct GpuWave {
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (full) flushed += 32u;
+        if (full) flushed += kFlush;
     }
     ALAC_DEV uint32_t st_finish() {
         for (uint32_t w = flushed; w < wcnt; ++w)
@@ -247,7 +268,7 @@ struct GpuWave {
         flushed = wcnt;
         return wcnt;
     }
-    /* bitstream ring of the entropy wave: 32 dwords per lane, rows of kRingStride dwords (16-byte aligned) */
+    /* bitstream ring of the entropy wave: kRingDw dwords per lane, rows of kRingStride dwords (16-byte aligned) */
     ALAC_DEV void ring_write4(uint32_t slot, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
         /* (slot >> 2) * 4 lets the compiler see the 16-byte alignment: one ds_write_b128 */
         *reinterpret_cast<uint4*>(&s_ring[lane * kRingStride + (slot >> 2) * 4u]) = make_uint4(a, b, c, d);
@@ -297,6 +318,7 @@ __global__ void alac_classify(alac::DevCfg cfg, const uint8_t* __restrict__ blob
                               const uint32_t* __restrict__ sizes, uint32_t n, uint16_t* __restrict__ keys, uint32_t* __restrict__ sizes_ws,
                               uint32_t* __restrict__ frames_out, int32_t* __restrict__ status, Plan* plan);
 __global__ void alac_plan(Plan* plan, uint32_t ppw);
+__global__ void alac_cu_census(uint32_t* __restrict__ seen, uint32_t* __restrict__ arrived, uint32_t expect);
 __global__ void alac_scatter(const uint16_t* __restrict__ keys, uint32_t n, Plan* plan, uint32_t* __restrict__ perm);
 __global__ void alac_task_classify(alac::DevCfg cfg, const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd,
                                    const uint16_t* __restrict__ pkt_keys, uint32_t n_slots, uint16_t* __restrict__ keys, Plan* plan);
@@ -311,14 +333,31 @@ __global__ void alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, 
                             const alac::PktDesc* __restrict__ pd, uint8_t* __restrict__ out, uint64_t out_stride,
                             uint32_t* __restrict__ frames_out, int32_t* __restrict__ status, int32_t* __restrict__ scratch_u,
                             int32_t* __restrict__ scratch_g, uint32_t ppw);
-__global__ void alac_decode(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
-                            const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
-                            uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
-                            int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, uint32_t ppw);
-__global__ void alac_decode_wide(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
-                                 const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
-                                 uint8_t* __restrict__ out, uint64_t out_stride, uint32_t* __restrict__ frames_out,
-                                 int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, uint32_t ppw);
+/* arguments of the pair kernels (k_decode_body.inc), passed as one struct */
+struct PairArgs {
+    alac::DevCfg cfg;
+    const uint8_t* blob;
+    uint64_t blob_bytes;
+    const uint64_t* offsets;
+    const uint32_t* sizes;
+    const uint32_t* perm;
+    Plan* plan;
+    uint8_t* out;
+    uint64_t out_stride;
+    uint32_t* frames_out;
+    int32_t* status;
+    int32_t* scratch_u;
+    const uint32_t* cu_number; /* 1 + the number of each CU (indexed like Plan::gate), 0 for CUs the census did not see */
+    uint32_t* claims; /* four words per wave slot of the plan, zeroed before every decode: whoever sets the first decodes the slot */
+    uint32_t ppw;
+    uint32_t n_cu; /* compute units of the device */
+    uint32_t cap;  /* pairs one of them holds */
+};
+#define ALAC_DECLARE_DECODE(NAME) __global__ void NAME(PairArgs);
+/* the wave pair over the regular packets, one kernel per class (sample width x channel width) */
+ALAC_DECLARE_DECODE(alac_decode_16) ALAC_DECLARE_DECODE(alac_decode_16g) ALAC_DECLARE_DECODE(alac_decode_24) ALAC_DECLARE_DECODE(alac_decode_32)
+ALAC_DECLARE_DECODE(alac_decode_w24) ALAC_DECLARE_DECODE(alac_decode_w32)
+#undef ALAC_DECLARE_DECODE
 __global__ void alac_chan_predict(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
                                   const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
                                   const alac::ChanDesc* __restrict__ cd, int32_t* __restrict__ rows, uint64_t row_stride, uint32_t ppw);

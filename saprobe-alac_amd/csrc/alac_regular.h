@@ -155,8 +155,8 @@ ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32
 }
 
 /* ---- the lean path's bit reader: an LDS ring per lane, refilled ahead of time --------------------------------
- * w0,w1 hold stream dwords widx, widx+1 and w2 the next one, as in FastRd, but they are fed from a 32-dword ring
- * in LDS (W::ring_*), never straight from HBM. The ring is topped up 16 bytes at a time on a wave-uniform
+ * w0,w1 hold stream dwords widx, widx+1 and w2 the next one, as in FastRd, but they are fed from a ring of
+ * W::kRingDw (16 or 32) dwords in LDS (W::ring_*), never straight from HBM. The ring is topped up 16 bytes at a time on a wave-uniform
  * schedule (every 4th step): tick() first commits the block whose global load was issued 4 steps earlier, then
  * issues the next one. So no step ever waits on an HBM/L2 round trip: the data a step needs left memory at
  * least four steps ago, and each packet byte is fetched from L2 exactly once. A plain step consumes <= 32 bits,
@@ -172,7 +172,8 @@ struct RingRd {
     uint32_t end_b;       /* first byte, counted from base, that is not packet data */
     uint32_t full;        /* dwords [0, full) of base lie wholly inside the packet */
     uint32_t w0, w1, w2, widx;
-    uint32_t fill;        /* ring holds dwords [fill-32, fill); multiple of 4 */
+    uint32_t fill;        /* ring holds dwords [fill - RING, fill); multiple of 4 */
+    static constexpr uint32_t RING = W::kRingDw;
     uint32_t p0, p1, p2, p3;
     bool pend;
 
@@ -209,7 +210,7 @@ struct RingRd {
         }
     }
     ALAC_DEV void commit(W& wv) {
-        wv.ring_write4(fill & 31u, __builtin_bswap32(p0), __builtin_bswap32(p1), __builtin_bswap32(p2),
+        wv.ring_write4(fill & (RING - 1u), __builtin_bswap32(p0), __builtin_bswap32(p1), __builtin_bswap32(p2),
                        __builtin_bswap32(p3));
         fill += 4u;
         pend = false;
@@ -236,9 +237,9 @@ struct RingRd {
             if (!pend) load4(fill);
             commit(wv);
         }
-        w0 = wv.ring_read(widx & 31u);
-        w1 = wv.ring_read((widx + 1u) & 31u);
-        w2 = wv.ring_read((widx + 2u) & 31u);
+        w0 = wv.ring_read(widx & (RING - 1u));
+        w1 = wv.ring_read((widx + 1u) & (RING - 1u));
+        w2 = wv.ring_read((widx + 2u) & (RING - 1u));
     }
     ALAC_DEV uint32_t window(uint32_t pos) const {
         const uint32_t r = (pos + bias) & 31u;
@@ -252,12 +253,12 @@ struct RingRd {
         w0 = (w1 & cm) | (w0 & ~cm);
         w1 = (w2 & cm) | (w1 & ~cm);
         widx = ni;
-        w2 = wv.ring_read((ni + 2u) & 31u);
+        w2 = wv.ring_read((ni + 2u) & (RING - 1u));
     }
     /* every 4th step, wave-uniform */
     ALAC_DEV void tick(W& wv) {
         if (pend) commit(wv);
-        if (fill + 4u <= widx + 32u) {
+        if (fill + 4u <= widx + RING) {
             load4(fill);
             pend = true;
         }

@@ -11,13 +11,13 @@
  *   alac_scatter   one thread per packet: counting-sort scatter into the lane permutation
  *   alac_scan      irregular packets, one wavefront per 64: status, frame count, where each channel starts; with
  *                  more than two channels also every channel's residuals, into the channel's row
- *   alac_decode / alac_decode_wide   regular packets: a PAIR of wavefronts per 64 same-key packets (alac_duo.h):
+ *   alac_decode_{16,24,32}, alac_decode_w{24,32}   regular packets: a PAIR of wavefronts per 64 same-key packets (alac_duo.h):
  *                  entropy wave and predictor / PCM wave, residuals through an LDS queue; PCM staged in LDS, written
- *                  as 128-B lines (two kernels: chanBits <= 23 and wider, one compilation unit each)
+ *                  in 64- or 128-B pieces (one kernel and compilation unit per class: sample width x chanBits)
  *   alac_task_classify / alac_plan / alac_scatter / alac_chan_predict   (> 2 channels) one wavefront per 64
  *                  (packet, channel) tasks of the same order: the predictor over the stored residuals, in place
  *   alac_interleave, alac_legacy   PCM of the scanned packets (frame order), whole-packet decoder for the rest
- * The kernels live in k_sort.hip, k_scan.hip, k_decode.hip, k_decode_wide.hip and k_split.hip (alac_gpu.h).
+ * The kernels live in k_sort.hip, k_scan.hip, k_dec*.hip and k_split.hip (alac_gpu.h).
  * HBM traffic per packet: compressed bytes in, PCM bytes out, plus the U-channel hand-off tile of stereo pairs
  * ((frame_length + 1) x 64 x int32 per workgroup, row-coalesced, written once and read once) or the sample rows
  * of the split pipeline.
@@ -203,13 +203,75 @@ struct alacgpu_decoder {
     Slot slots[kSlots];                                      /* host-entry staging */
     CopyPool* pool;
     uint32_t il_threads;                                     /* alac_interleave block size (64, 128 or 256) */
+    uint32_t n_cu;                                           /* compute units of the device */
+    DevBuf cu_number;                                        /* PairArgs::cu_number */
     size_t chunk_bytes;                                      /* host entry: target bytes (in + out) per chunk */
 };
 
 namespace {
 
-/* upper bound on the waves of a batch: every key present may end in one partly filled wave */
-size_t max_waves(size_t n, uint32_t ppw) { return (n + ppw - 1) / ppw + std::min<size_t>(n, 18 * 18 + 8); }
+size_t plan_claims_offset() { return (sizeof(Plan) + 255u) & ~(size_t)255u; }
+size_t plan_bytes(size_t waves) { return plan_claims_offset() + waves * 4 * sizeof(uint32_t); }
+
+/* wave pairs of a pair kernel one CU holds at a time (registers and LDS, as the runtime computes it); asked once per kernel */
+template <class K>
+uint32_t pair_capacity(K kernel) {
+    static std::atomic<int> cached{0}; /* one instantiation per kernel; every device here is the same model */
+    int v = cached.load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, (int)(2 * kWave), 0) != hipSuccess || v <= 0) v = 4;
+        if (const char* e = getenv("ALACGPU_PAIR_CAP")) { /* experiments: fewer pairs per CU than would fit */
+            const int lim = atoi(e);
+            if (lim >= 1 && lim < v) v = lim;
+        }
+        cached.store(v, std::memory_order_relaxed);
+    }
+    return (uint32_t)v;
+}
+
+/* Numbers the device's compute units for the pair kernels (k_decode_body.inc): XCD by XCD, so that CU number c is on
+ * XCD c mod 8 when there are eight of them; within an XCD in the order of the hardware ids. The table is indexed by
+ * XCC_ID << 6 | SE << 4 | CU and holds number + 1. */
+int cu_numbers(alacgpu_decoder* dec) {
+    int rc;
+    if ((rc = dec->cu_number.ensure(513 * sizeof(uint32_t)))) return rc;
+    HIP_TRY(hipMemsetAsync(dec->cu_number.p, 0, 513 * sizeof(uint32_t), dec->stream));
+    hipLaunchKernelGGL(alac_cu_census, dim3(2 * dec->n_cu), dim3(kWave), 0, dec->stream, (uint32_t*)dec->cu_number.p,
+                       (uint32_t*)dec->cu_number.p + 512, 2 * dec->n_cu);
+    HIP_TRY(hipGetLastError());
+    uint32_t seen[512];
+    HIP_TRY(hipMemcpyAsync(seen, dec->cu_number.p, sizeof(seen), hipMemcpyDeviceToHost, dec->stream));
+    HIP_TRY(hipStreamSynchronize(dec->stream));
+    uint32_t per_xcd[8] = {0}, xcds = 0, total = 0;
+    for (uint32_t i = 0; i < 512; i++)
+        if (seen[i]) {
+            per_xcd[i >> 6]++;
+            total++;
+        }
+    for (uint32_t x = 0; x < 8; x++) xcds += per_xcd[x] ? 1u : 0u;
+    if (xcds == 0) xcds = 1;
+    uint32_t next[8] = {0}, order[8] = {0}, k = 0;
+    for (uint32_t x = 0; x < 8; x++)
+        if (per_xcd[x]) order[x] = k++;
+    for (uint32_t i = 0; i < 512; i++)
+        if (seen[i]) {
+            const uint32_t x = i >> 6;
+            seen[i] = 1u + next[x]++ * xcds + order[x]; /* numbers above n_cu (uneven XCDs) only ever take what is left */
+        }
+    if (total > dec->n_cu) dec->n_cu = total;
+    HIP_TRY(hipMemcpyAsync(dec->cu_number.p, seen, sizeof(seen), hipMemcpyHostToDevice, dec->stream));
+    HIP_TRY(hipStreamSynchronize(dec->stream));
+    return ALACGPU_E_OK;
+}
+
+/* upper bound on the waves of a batch: every key present may end in one partly filled wave. Regular keys: 18 x 18 pairs
+ * of predictor orders (0..16 and 31), once more for the wide channels that only 24- and 32-bit streams can have
+ * (alac_regular.h: chanBits > 23), plus the irregular keys. */
+size_t max_waves(uint32_t bit_depth, size_t n, uint32_t ppw) {
+    const size_t keys = (bit_depth >= 24 ? 2 : 1) * 18 * 18 + 8;
+    return (n + ppw - 1) / ppw + std::min<size_t>(n, keys);
+}
+size_t max_waves(const alacgpu_decoder* dec, size_t n, uint32_t ppw) { return max_waves(dec->cfg.bit_depth, n, ppw); }
 
 /* Packets per wave. A VALU instruction costs the SIMD the same whether 64 lanes or 8 are live (profiles/microbench/
  * valu_multi_mi355x.txt, "half" rows), so waves are kept full while there is at least one workgroup per CU (256); a
@@ -230,11 +292,12 @@ uint32_t pick_ppw(size_t n) {
 size_t row_stride_of(uint32_t frame_length) { return ((size_t)frame_length + 3u) & ~(size_t)3u; } /* 16-byte rows */
 
 int reserve_workspace(alacgpu_decoder* dec, size_t n, uint32_t ppw) {
-    const size_t waves = max_waves(n, ppw);
+    const size_t waves = max_waves(dec, n, ppw);
     int rc;
     if ((rc = dec->scratch_u.ensure(waves * u_tile_cells(dec->cfg.frame_length) * sizeof(int32_t)))) return rc;
     if ((rc = dec->scratch_g.ensure(waves * kFallbackSlots * ppw * sizeof(int32_t)))) return rc;
-    if ((rc = dec->plan.ensure(sizeof(Plan)))) return rc;
+    /* the plan and, behind it, the claim flags of the pair kernels (one per wave slot): zeroed together */
+    if ((rc = dec->plan.ensure(plan_bytes(waves)))) return rc;
     if ((rc = dec->cls.ensure((n ? n : 1) * sizeof(uint16_t)))) return rc;
     if ((rc = dec->perm.ensure((n ? n : 1) * sizeof(uint32_t)))) return rc;
     if ((rc = dec->sizes_ws.ensure((n ? n : 1) * sizeof(uint32_t)))) return rc;
@@ -270,27 +333,44 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
     const uint32_t nb = (uint32_t)((n + 255) / 256);
     const uint32_t slot = (uint32_t)(dec->launches % kTimingSlots);
     HIP_TRY(hipEventRecord(dec->ev_start[slot], dec->stream));
-    HIP_TRY(hipMemsetAsync(plan, 0, sizeof(Plan), dec->stream));
+    HIP_TRY(hipMemsetAsync(plan, 0, plan_bytes(max_waves(dec, n, ppw)), dec->stream));
     hipLaunchKernelGGL(alac_classify, dim3(nb), dim3(256), 0, dec->stream, c, d_blob, blob_bytes, d_offsets, d_sizes,
                        (uint32_t)n, (uint16_t*)dec->cls.p, (uint32_t*)dec->sizes_ws.p, d_frames, d_status, plan);
     hipLaunchKernelGGL(alac_plan, dim3(1), dim3(kWave), 0, dec->stream, plan, ppw);
     hipLaunchKernelGGL(alac_scatter, dim3(nb), dim3(256), 0, dec->stream, (const uint16_t*)dec->cls.p, (uint32_t)n, plan,
                        (uint32_t*)dec->perm.p);
     /* irregular packets first (usually a handful of waves, or none), then the wave pairs of the regular ones */
-    hipLaunchKernelGGL(alac_scan, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, blob_bytes,
+    hipLaunchKernelGGL(alac_scan, dim3((uint32_t)max_waves(dec, n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, blob_bytes,
                        d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride, d_frames,
                        d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw, (alac::ChanDesc*)dec->cd.p,
                        (alac::PktDesc*)dec->pd.p, dec->cfg.num_channels > 2 ? (int32_t*)dec->rows.p : (int32_t*)nullptr,
                        (uint64_t)row_stride_of(dec->cfg.frame_length));
     if (dec->cfg.num_channels <= 2 && dec->cfg.kb != 0) {
-        hipLaunchKernelGGL(alac_decode, dim3((uint32_t)max_waves(n, ppw)), dim3(2 * kWave), 0, dec->stream, c, d_blob,
-                           blob_bytes, d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out,
-                           (uint64_t)out_stride, d_frames, d_status, (int32_t*)dec->scratch_u.p, ppw);
-        /* chanBits > 23 only exists at 24 and 32 bits (without their usual shift bytes) */
-        if (dec->cfg.bit_depth >= 24)
-            hipLaunchKernelGGL(alac_decode_wide, dim3((uint32_t)max_waves(n, ppw)), dim3(2 * kWave), 0, dec->stream, c, d_blob,
-                               blob_bytes, d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out,
-                               (uint64_t)out_stride, d_frames, d_status, (int32_t*)dec->scratch_u.p, ppw);
+        /* one kernel per class of regular packets (alac_gpu.h, k_decode_body.inc): each one is launched over all the wave
+         * slots and leaves the slots of the other classes alone. gated_cap: how many pairs per CU the gated twin of the
+         * kernel can hold (0: it has none); which of the twins works is decided on the device. */
+        PairArgs a{c, d_blob, (uint64_t)blob_bytes, d_offsets, sz, (const uint32_t*)dec->perm.p, plan, d_out, (uint64_t)out_stride,
+                   d_frames, d_status, (int32_t*)dec->scratch_u.p, (const uint32_t*)dec->cu_number.p,
+                   (uint32_t*)((uint8_t*)plan + plan_claims_offset()), ppw, dec->n_cu, 0u};
+        const uint32_t slots = (uint32_t)max_waves(dec, n, ppw);
+        auto pairs = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(slots), dim3(2 * kWave), 0, dec->stream, a); };
+        switch (dec->cfg.bit_depth) {
+            case 16:
+                a.cap = pair_capacity(alac_decode_16g);
+                pairs(alac_decode_16);
+                /* as many workgroups as the device holds at once: they share the slots out among themselves */
+                if ((size_t)slots > (size_t)4 * dec->n_cu && a.cap > 4u)
+                    hipLaunchKernelGGL(alac_decode_16g, dim3(std::min<uint32_t>(a.cap * dec->n_cu, slots)), dim3(2 * kWave), 0,
+                                       dec->stream, a);
+                break;
+            case 32:
+                pairs(alac_decode_32);
+                pairs(alac_decode_w32); /* chanBits > 23 only exists at 24 and 32 bits (without their usual shift bytes) */
+                break;
+            default: /* 20 and 24 */
+                pairs(alac_decode_24);
+                if (dec->cfg.bit_depth == 24) pairs(alac_decode_w24);
+        }
     }
     HIP_TRY(hipGetLastError());
     if (dec->cfg.kb != 0) {
@@ -313,7 +393,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
             hipLaunchKernelGGL(alac_plan, dim3(1), dim3(kWave), 0, dec->stream, plan2, ppw2);
             hipLaunchKernelGGL(alac_scatter, dim3(nb2), dim3(256), 0, dec->stream, (const uint16_t*)dec->keys2.p,
                                (uint32_t)n_slots, plan2, (uint32_t*)dec->perm2.p);
-            hipLaunchKernelGGL(alac_chan_predict, dim3((uint32_t)max_waves(n_slots, ppw2)), dim3(kWave), 0, dec->stream, c,
+            hipLaunchKernelGGL(alac_chan_predict, dim3((uint32_t)max_waves(16u, n_slots, ppw2)), dim3(kWave), 0, dec->stream, c,
                                d_blob, blob_bytes, d_offsets, sz, (const uint32_t*)dec->perm2.p, (const Plan*)plan2,
                                (const alac::ChanDesc*)dec->cd.p, (int32_t*)dec->rows.p, rs, ppw2);
         }
@@ -322,7 +402,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
         hipLaunchKernelGGL(alac_interleave, dim3(ib), dim3(il_threads), 32u * il_threads, dec->stream, c, d_blob, blob_bytes, d_offsets, sz,
                            (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::ChanDesc*)dec->cd.p,
                            (const alac::PktDesc*)dec->pd.p, (const int32_t*)dec->rows.p, rs, d_out, (uint64_t)out_stride, bpp);
-        hipLaunchKernelGGL(alac_legacy, dim3((uint32_t)max_waves(n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, blob_bytes,
+        hipLaunchKernelGGL(alac_legacy, dim3((uint32_t)max_waves(dec, n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, blob_bytes,
                            d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::PktDesc*)dec->pd.p, d_out,
                            (uint64_t)out_stride, d_frames, d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw);
         HIP_TRY(hipGetLastError());
@@ -378,6 +458,11 @@ int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out)
     d->launches = 0;
     d->pool = nullptr;
     d->il_threads = 64;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
+        d->n_cu = cus > 0 ? (uint32_t)cus : 256u;
+    }
     if (const char* e = getenv("ALACGPU_IL_THREADS")) {
         const int v = atoi(e);
         if (v == 64 || v == 128 || v == 256) d->il_threads = (uint32_t)v;
@@ -406,6 +491,10 @@ int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out)
         alacgpu_destroy(d);
         return ALACGPU_E_HIP;
     }
+    if (int rc = cu_numbers(d)) {
+        alacgpu_destroy(d);
+        return rc;
+    }
     *out = d;
     return ALACGPU_E_OK;
 }
@@ -417,7 +506,7 @@ void alacgpu_destroy(alacgpu_decoder* d) {
     if (d->s_in) (void)hipStreamSynchronize(d->s_in);
     if (d->s_out) (void)hipStreamSynchronize(d->s_out);
     delete d->pool;
-    DevBuf* bufs[] = {&d->scratch_u, &d->scratch_g, &d->plan, &d->cls, &d->perm, &d->sizes_ws, &d->cd, &d->pd,
+    DevBuf* bufs[] = {&d->cu_number, &d->scratch_u, &d->scratch_g, &d->plan, &d->cls, &d->perm, &d->sizes_ws, &d->cd, &d->pd,
                       &d->plan2, &d->keys2, &d->perm2, &d->rows};
     for (DevBuf* b : bufs) b->release();
     for (int k = 0; k < kSlots; k++) {
@@ -655,6 +744,21 @@ int alacgpu_kernel_times(alacgpu_decoder* d, float* ms, size_t max_n, size_t* n_
         const uint32_t slot = (uint32_t)((d->launches - n + i) % kTimingSlots);
         HIP_TRY(hipEventElapsedTime(&ms[i], d->ev_start[slot], d->ev_stop[slot]));
     }
+    *n_out = n;
+    return ALACGPU_E_OK;
+}
+
+int alacgpu_pair_placement(alacgpu_decoder* d, uint32_t* tags, size_t max_n, size_t* n_out) {
+    if (!d || !tags || !n_out) return ALACGPU_E_ARG;
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    *n_out = 0;
+    if (!d->plan.p) return ALACGPU_E_OK;
+    Plan head;
+    HIP_TRY(hipMemcpy(&head, d->plan.p, sizeof(Plan), hipMemcpyDeviceToHost));
+    const size_t n = std::min<size_t>(head.total_waves, max_n / 4);
+    if (plan_bytes(n) > d->plan.cap) return ALACGPU_E_ARG;
+    if (n) HIP_TRY(hipMemcpy(tags, (const uint8_t*)d->plan.p + plan_claims_offset(), n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     *n_out = n;
     return ALACGPU_E_OK;
 }

@@ -1,0 +1,19 @@
+/*
+ * k_decw24.hip — the wave pair of alac_duo.h for one class of regular packets: 20/24-bit (3-byte) samples, chanBits 24..33 (no shift bytes) (one translation
+ * unit of libalacgpu.so, see alac_gpu.h; the kernel body is k_decode_body.inc). The compiler sizes a kernel by its
+ * largest variant, so the sample widths are separate kernels — a handle only ever launches the ones of its own
+ * width — and the units compile in parallel.
+ */
+#include "alac_gpu.h"
+
+#define ALAC_DECODE_KERNEL alac_decode_w24
+#define ALAC_DECODE_WIDE 1
+#define ALAC_DECODE_DEPTH 24
+#define ALAC_DECODE_GATED 0
+#define ALAC_DECODE_WAVES 2 /* __launch_bounds__: waves per SIMD the register budget must allow */
+
+namespace alack {
+
+#include "k_decode_body.inc"
+
+} /* namespace alack */

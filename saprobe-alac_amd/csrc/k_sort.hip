@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(kWave) alac_plan(Plan* plan, uint32_t ppw) {
     __syncthreads();
     constexpr uint32_t R = (kKeys + kWave - 1) / kWave;
     const uint32_t q0 = threadIdx.x * R; /* dispatch position q holds key kKeys - 1 - q */
-    uint32_t p = 0, w = 0, z = 0, wi = 0;
+    uint32_t p = 0, w = 0, z = 0, wi = 0, ww = 0;
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t q = q0 + r;
         if (q >= kKeys) break;
@@ -72,14 +72,17 @@ __global__ void __launch_bounds__(kWave) alac_plan(Plan* plan, uint32_t ppw) {
         w += cw;
         z += c ? 1u : 0u;
         wi += key >= alac::KEY_IRREGULAR ? cw : 0u;
+        ww += (key >= alac::KEY_WIDE && key < alac::KEY_IRREGULAR) ? cw : 0u;
     }
     /* inclusive scan over the 64 lanes, then make it exclusive */
-    uint32_t ip = p, iw = w, iz = z, ii = wi;
+    uint32_t ip = p, iw = w, iz = z, ii = wi, ix = ww;
 #pragma unroll
     for (int o = 1; o < (int)kWave; o <<= 1) {
         const uint32_t tp = (uint32_t)__shfl_up((int)ip, o, kWave), tw = (uint32_t)__shfl_up((int)iw, o, kWave);
         const uint32_t tz = (uint32_t)__shfl_up((int)iz, o, kWave), ti = (uint32_t)__shfl_up((int)ii, o, kWave);
+        const uint32_t tx = (uint32_t)__shfl_up((int)ix, o, kWave);
         if ((int)threadIdx.x >= o) {
+            ix += tx;
             ip += tp;
             iw += tw;
             iz += tz;
@@ -106,6 +109,7 @@ __global__ void __launch_bounds__(kWave) alac_plan(Plan* plan, uint32_t ppw) {
         plan->nk = iz;
         plan->total_waves = iw;
         plan->irr_waves = ii;
+        plan->wide_waves = ix;
     }
 }
 
@@ -155,6 +159,25 @@ alac_task_classify(alac::DevCfg cfg, const alac::ChanDesc* __restrict__ cd, cons
     }
     __syncthreads();
     if (threadIdx.x < alac::NUM_TASK_KEYS && hist[threadIdx.x]) atomicAdd(&plan->count[threadIdx.x], hist[threadIdx.x]);
+}
+
+/* Which compute units does this device have? Every workgroup marks the one it runs on (same numbering as the pair
+ * kernels' gate: XCC_ID << 6 | SE << 4 | CU of HW_ID). 64 KB of LDS each = two workgroups per CU, and the grid is two
+ * per CU, so the dispatcher has to use every CU; a workgroup stays until all have arrived (or, on a busy device, for a
+ * bounded time: a CU that is missed only loses its fixed place in the pair kernels' item order). Run once per handle. */
+__global__ void __launch_bounds__(kWave) alac_cu_census(uint32_t* __restrict__ seen, uint32_t* __restrict__ arrived, uint32_t expect) {
+    __shared__ uint32_t pad[16384];
+    pad[threadIdx.x] = threadIdx.x;
+    if (threadIdx.x == 0) {
+        uint32_t id, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        seen[((xcc & 7u) << 6) | (((id >> 13) & 3u) << 4) | ((id >> 8) & 15u)] = 1u;
+        atomicAdd(arrived, 1u);
+        for (int i = 0; i < 4000 && atomicAdd(arrived, 0u) < expect; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+    __syncthreads();
+    if (pad[(threadIdx.x * 5u) & 63u] == 0xffffffffu) seen[0] = 2u; /* keeps the LDS block allocated */
 }
 
 } /* namespace alack */

@@ -27,6 +27,7 @@ namespace {
 /* one-lane wave: collectives are identities, the stager writes straight to the PCM slot */
 struct HostWave {
     static constexpr bool kResMem = false;
+    static constexpr uint32_t kRingDw = 32; /* alac_gpu.h: ALAC_LDS_RING */
     std::vector<int32_t> u_tile, g_tile;
     uint8_t* st_out = nullptr;
     uint32_t st_cnt = 0;

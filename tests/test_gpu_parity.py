@@ -310,3 +310,41 @@ def test_baseline_configs_c_and_d_at_full_size(pkg, synth, oracle, gpu_decoder_f
         del exp
     ref = oracle.decode_batch(cfg, b.blob, b.offsets[:128], b.sizes[:128], threads=8)
     assert np.array_equal(ref[0], d_out[:128].cpu().numpy())
+
+
+@pytest.mark.parametrize("n,fl,profile", [(70000, 64, 0), (98304, 40, 0), (150000, 33, 3), (66000, 48, 2)])
+def test_batches_between_the_rounds_take_the_gated_pairs(pkg, synth, oracle, helpers, gpu_decoder_factory, n, fl, profile):
+    """16-bit batches of more than 4 x CUs wave slots but less than the next multiple (k_decode_body.inc): the gated
+    kernel decodes them with five or six pairs per CU. Every regular slot is decoded exactly once by some pair, no CU
+    admits more pairs than its quota — and the PCM is the oracle's (DynDecomp / UnpcBlock / WriteStereo16, golomb.go:148, predictor.go:45, matrix.go:30)."""
+    import torch
+    cfg = oracle.make_config(fl, 16, 2)
+    b = synth.gen_batch(cfg, n, profile=profile, threads=16)
+    dev = torch.device("cuda:0")
+    stride = fl * 4
+    d_blob = torch.from_numpy(b.blob).to(dev)
+    d_off = torch.from_numpy(b.offsets.astype(np.int64)).to(dev)
+    d_sz = torch.from_numpy(b.sizes.astype(np.int32)).to(dev)
+    d_out = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    d_fr = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with gpu_decoder_factory(cfg) as dec:
+        dec.decode_batch_device(d_blob.data_ptr(), d_blob.numel(), d_off.data_ptr(), d_sz.data_ptr(), n, d_out.data_ptr(),
+                                stride, d_fr.data_ptr(), d_st.data_ptr(), sync=True)
+        place = dec.pair_placement()
+    ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=16)
+    got = (d_out.cpu().numpy(), d_fr.cpu().numpy().astype(np.uint32), d_st.cpu().numpy())
+    helpers.assert_same_decode(cfg, ref, got, 4, "n=%d" % n)
+    tags = place[:, 0]
+    owned = tags[tags != 0]
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    slots = len(tags)
+    if slots > 4 * n_cu and slots <= 6 * n_cu:  # otherwise pair_quota leaves the batch to the ungated kernel
+        assert len(owned) >= slots - 24 and (owned >> 31).all()  # all but the irregular slots, each tagged once
+        cu = (owned >> 8) & 0x1ff
+        first = owned[(owned & 1) == 0]  # a pair's first item; bit 0 marks the ones it took afterwards
+        per_cu = np.bincount(((first >> 8) & 0x1ff).astype(np.int64), minlength=512)
+        # (with frames this short the first pairs are done before the last ones arrive, so only the ceiling is firm)
+        assert len(np.unique(cu)) > n_cu // 2 and per_cu.max() <= 6
+        assert (place[tags != 0, 2] != place[tags != 0, 1]).all()  # start and end clocks recorded

@@ -92,7 +92,7 @@ def main():
         m = np.array(bd["ms"])
         print(json.dumps({"lib": bd["path"], "version": bd["version"], "median_ms": round(float(np.median(m)), 4),
                           "min_ms": round(float(m.min()), 4), "max_ms": round(float(m.max()), 4), "n": len(m),
-                          "bit_exact": bd["bit_exact"], "note": "0.2.x brackets exclude the sort pre-pass (~20 us)" if bd["old"] else ""}))
+                          "bit_exact": bd["bit_exact"], "all_ms": [round(float(x), 3) for x in m] if os.environ.get("AB_DUMP") else None, "note": "0.2.x brackets exclude the sort pre-pass (~20 us)" if bd["old"] else ""}))
         bd["L"].alacgpu_destroy(bd["h"])
 
 
