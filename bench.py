@@ -254,7 +254,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None,
                          "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload and this source)") if traffic else None,
-                         "kernel": "alac_decode" if ch <= 2 else "alac_scan + alac_chan_predict + alac_interleave",
+                         "kernel": ("alac_decode_%s" % {16: "16 (alac_decode_16g between the rounds)", 20: "24", 24: "24", 32: "32"}[depth]) if ch <= 2
+                         else "alac_scan + alac_chan_predict + alac_interleave",
                          "kernel_ms": round(kernel_ms, 4), "kernel_ms_is": "HIP events on the handle's stream around all kernels of one decode (sort pre-pass included)",
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu, "bit_exact": bit_exact, "gen_seconds": round(gen_s, 2), "host_entry": host_entry,

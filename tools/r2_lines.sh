@@ -9,11 +9,11 @@ $B --depth 24 --channels 8 --packets 16384           > $OUT/config_d_8ch_16384.j
 $B --depth 24 --channels 8 --packets 65536 --steps 3 > $OUT/config_d_8ch_65536.json 2>/dev/null
 $B --depth 20                                        > $OUT/f4_20bit_stereo.json 2>/dev/null
 $B --depth 32                                        > $OUT/f4_32bit_stereo_shift2.json 2>/dev/null
-$B --depth 32 --profile 5                            > $OUT/f4_32bit_stereo_shift0_wide.json 2>/dev/null
+$B --depth 32 --channels 1 --profile 5               > $OUT/f4_32bit_mono_shift0_wide.json 2>/dev/null
 $B --depth 24 --profile 5                            > $OUT/f4_24bit_stereo_shift0_wide.json 2>/dev/null
 $B --channels 1                                      > $OUT/f4_16bit_mono.json 2>/dev/null
 $B --channels 6 --packets 21845                      > $OUT/f4_16bit_5_1.json 2>/dev/null
-for p in 32768 66000 70000 98304 131072; do $B --packets $p > $OUT/sweep_$p.json 2>/dev/null; done
+for p in 32768 66000 70000 81920 98304 114688 131072 196608; do $B --packets $p > $OUT/sweep_$p.json 2>/dev/null; done
 $B --profile 6                                       > $OUT/mixed_orders_9keys.json 2>/dev/null
 $B --profile 6 --packets 70000                       > $OUT/mixed_orders_9keys_70000.json 2>/dev/null
 python - "$OUT" <<'PY'
