@@ -177,8 +177,8 @@ int alacgpu_kernel_times(alacgpu_decoder* dec, float* ms, size_t max_n, size_t* 
  * slot of the launch plan (irregular packets first, then wide keys, then narrow ones, slowest first; n_out counts
  * slots, max_n words): [0] is 0 for slots that no wave pair owns (the irregular ones), else bit 31 | SIMD of the
  * predictor wave << 19 | SIMD of the entropy wave << 17 | CU number << 8 | the pair's arrival number on its CU << 4 |
- * bit 0 set when the pair took the slot after finishing another; [1], [2] the low words of the device's constant
- * 100 MHz clock when the pair began and ended the slot; [3] unused. tests/test_gpu_parity.py checks the spread over
+ * bit 0 set when the pair took the slot after finishing another; [1], [2] the low words of the wave's
+ * s_memtime counter (about 2.1 GHz on MI355X) when the pair began and ended the slot; [3] unused. tests/test_gpu_parity.py checks the spread over
  * the CUs, tools/pair_placement.py prints it. */
 int alacgpu_pair_placement(alacgpu_decoder* dec, uint32_t* tags, size_t max_n, size_t* n_out);
 

@@ -2,8 +2,8 @@
  * alac_gpu.h — what the kernel translation units of libalacgpu.so share: the gfx950 forms of the building-block
  * macros of alac_regular.h, the wave policies (GpuWave: LDS stager, bitstream rings, residual queue, DPP reductions;
  * GpuWaveMem: residuals from memory), the launch plan, and the kernels' declarations. The library is built from
- * several translation units (k_sort, k_scan, k_decode, k_decode_wide, k_split, alacgpu) so that the kernels compile in
- * parallel; nothing crosses between them on the device side.
+ * several translation units (k_sort, k_scan, k_dec16, k_dec16g, k_dec24, k_dec32, k_decw24, k_decw32, k_split, alacgpu)
+ * so that the kernels compile in parallel; nothing crosses between them on the device side.
  */
 #ifndef ALAC_GPU_H
 #define ALAC_GPU_H
@@ -100,7 +100,7 @@ static __device__ unsigned long long g_duo_prof[16];
 #include "alac_duo.h"
 #include "alac_split.h"
 
-/* s_setprio levels of the wave pair (see alac_decode) */
+/* s_setprio levels of the wave pair (see k_decode_body.inc: pair_item) */
 #ifndef ALAC_PRIO_B_LONG
 #define ALAC_PRIO_B_LONG 3  /* predictor waves, order > 8 */
 #define ALAC_PRIO_B_MID 2   /* order 6..8 */

@@ -55,7 +55,7 @@ alac_scan(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_byte
     }
 }
 
-/* packets the scan routed to the whole-packet decoder (orders 17..30): same wave mapping as alac_decode */
+/* packets the scan routed to the whole-packet decoder (orders 17..30): same wave mapping as the ungated pair kernels */
 __global__ void __launch_bounds__(kWave)
 alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
             const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,

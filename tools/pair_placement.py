@@ -75,27 +75,29 @@ def main():
         per_simd[(c, a)][0] += 1
         per_simd[(c, b_)][1] += 1
     print("SIMD loads (entropy waves, predictor waves) histogram:", sorted(collections.Counter(tuple(v) for v in per_simd.values()).items()))
-    # timing: 100 MHz ticks -> microseconds relative to the earliest start
+    # timing: s_memtime ticks (about 2.1 GHz on MI355X), shown in thousands, relative to the earliest start
     first = int(np.argmax(tags != 0))
     t0 = owned_rows[:, 1].astype(np.int64)
     t1 = owned_rows[:, 2].astype(np.int64)
     base = t0.min()
-    beg, end = (t0 - base) / 100.0, ((t1 - base) % (1 << 32)) / 100.0
+    t0 = np.where(t0 == 0, t0.max(), t0)
+    base = t0.min()
+    beg, end = ((t0 - base) % (1 << 32)) / 1000.0, ((t1 - base) % (1 << 32)) / 1000.0
     idx = np.nonzero(tags != 0)[0] - first
-    print("pairs: first start 0, last start %.0f us, last end %.0f us" % (beg.max(), end.max()))
+    print("pairs (kiloticks): first start 0, last start %.0f, last end %.0f" % (beg.max(), end.max()))
     edges = np.linspace(0, idx.max() + 1, 9).astype(int)
     for lo, hi in zip(edges[:-1], edges[1:]):
         m = (idx >= lo) & (idx < hi)
         if m.any():
-            print("  items %4d..%4d: duration mean %.0f max %.0f us, end max %.0f us" % (lo, hi - 1, (end - beg)[m].mean(), (end - beg)[m].max(), end[m].max()))
+            print("  items %4d..%4d: duration mean %.0f max %.0f, end max %.0f" % (lo, hi - 1, (end - beg)[m].mean(), (end - beg)[m].max(), end[m].max()))
     late = np.argsort(-end)[:8]
     by_cu = collections.defaultdict(list)
     for k in range(owned.size):
         by_cu[int(cu[k])].append(k)
-    print("the pairs that end last, with the others on their CU (item:arrival:entropy SIMD:predictor SIMD:end us):")
+    print("the pairs that end last, with the others on their CU (item:arrival:entropy SIMD:predictor SIMD:end):")
     for k in late:
         mates = by_cu[int(cu[k])]
-        print("  item %4d ends %.0f us on CU %3d:" % (idx[k], end[k], cu[k]),
+        print("  item %4d ends %.0f on CU %3d:" % (idx[k], end[k], cu[k]),
               " ".join("%d:%d:%d:%d:%.0f" % (idx[m], slot[m], sa[m], sb[m], end[m]) for m in mates))
 
 
