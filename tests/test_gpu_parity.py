@@ -348,3 +348,38 @@ def test_batches_between_the_rounds_take_the_gated_pairs(pkg, synth, oracle, hel
         # (with frames this short the first pairs are done before the last ones arrive, so only the ceiling is firm)
         assert len(np.unique(cu)) > n_cu // 2 and per_cu.max() <= 6
         assert (place[tags != 0, 2] != place[tags != 0, 1]).all()  # start and end clocks recorded
+
+
+def test_gated_pairs_with_corrupt_packets_and_two_handles_at_once(pkg, synth, oracle, helpers, gpu_decoder_factory):
+    """The gated kernel under the conditions the small-batch tests never reach it in: a batch of 84 000 packets of which
+    every tenth is damaged (the status words of DynDecomp's error paths, golomb.go:157-163,196-199,239-245, must be the
+    oracle's and the neighbours unharmed), decoded by two handles from two threads at the same time — their workgroups
+    compete for the CUs, so neither finds the residency its gate assumes; the sweep has to pick up the rest."""
+    import threading
+    fl, n = 40, 84000
+    cfg = oracle.make_config(fl, 16, 2)
+    rng = np.random.default_rng(7)
+    b = synth.gen_batch(cfg, n, profile=synth.PROFILE_MUSIC, threads=16)
+    packets = [b.packet(i) for i in range(n)]
+    bad = helpers.mutate_packets(b, rng, n // 10)
+    for k, p in enumerate(bad):
+        packets[k * 10 + 3] = p
+    blob, offs, sizes = helpers.pack_dense(packets, lead=1)
+    ref = oracle.decode_batch(cfg, *helpers.pack_packets(packets), threads=16)
+    assert len(np.unique(ref[2])) > 3
+    results, gated = [None, None], [False, False]
+
+    def work(k):
+        with gpu_decoder_factory(cfg) as dec:
+            for _ in range(3):
+                results[k] = _gpu_decode(dec, blob, offs, sizes)
+            gated[k] = bool((dec.pair_placement()[:, 0] != 0).any())
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(2):
+        helpers.assert_same_decode(cfg, ref, results[k], 4, "handle %d" % k)
+    assert all(gated)  # the batch really went through alac_decode_16g
