@@ -22,6 +22,9 @@ for r in range(rounds):
     prof = int(rng.choice([synth.PROFILE_MUSIC, synth.PROFILE_NOISE, synth.PROFILE_QUIET, synth.PROFILE_STRESS,
                            synth.PROFILE_STRESS, synth.PROFILE_MUSIC_NOSHIFT, synth.PROFILE_MUSIC_MIXED]))
     n = int(rng.choice([1, 7, 64, 65, 200, 700]))
+    if rng.integers(12) == 0 and fl < 70:  # batches big enough for the gated pair kernel (16-bit) / a second round (others)
+        n = int(rng.choice([66000, 70000, 99000, 132000]))
+        ch = int(rng.choice([1, 2, 2]))
     ppw = rng.choice(["", "64", "16", "2"])
     if ppw:
         os.environ["ALACGPU_PPW"] = str(ppw)
