@@ -1,15 +1,16 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): profiles/collect_round.sh <outdir>
-# The evidence of one round for the headline workload (bench.py's default command):
+# usage (on the GPU box, from the repo root): profiles/collect_round.sh <outdir> [bench.py workload flags, e.g. --depth 24]
+# The evidence of one round for the headline workload (bench.py's default command) or for another configuration:
 #   kernel_stats.csv       rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-host-entry`
 #   bench_under_rocprof.json   the bench line of that same run
 #   pmc_summary.txt        instruction / cycle counters (one --pmc pass per line of groups_duo.txt, never mixed with traces)
 #   traffic.json           HBM bytes per launch: FETCH_SIZE x 2 (gfx950 counts 128-B requests as 64) + WRITE_SIZE, stamped with
 #                          the sha256 of the kernel sources so that bench.py only quotes it for the binary it was taken from
 set -u
-OUT=$1; mkdir -p "$OUT"
+OUT=$1; shift; mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-host-entry"
+WORKLOAD="$*"
+CMD="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-host-entry $WORKLOAD"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $CMD > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 cp $(find "$OUT/trace" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"
 head -40 $(find "$OUT/trace" -name "*kernel_trace.csv" | head -1) > "$OUT/kernel_trace_head.csv"
@@ -18,9 +19,9 @@ i=0
 while read -r grp; do
   [ -z "$grp" ] && continue
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pass$i" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-entry --no-verify > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed: $grp" >> "$OUT/failed.txt"
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pass$i" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-entry --no-verify $WORKLOAD > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed: $grp" >> "$OUT/failed.txt"
 done < <(cat profiles/groups_duo.txt profiles/groups_traffic.txt)
-python3 - "$OUT" <<'PY'
+python3 - "$OUT" "$WORKLOAD" <<'PY'
 import csv, glob, json, os, sys, collections, importlib
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -38,7 +39,12 @@ pkg = importlib.import_module("saprobe-alac_amd")
 mean = lambda k, c: (sum(agg[k][c]) / len(agg[k][c])) if agg[k].get(c) else 0.0
 fetch = sum(mean(k, "FETCH_SIZE") for k in agg if "alac" in k) * 1024   # KB
 write = sum(mean(k, "WRITE_SIZE") for k in agg if "alac" in k) * 1024
-json.dump({"workload": [16, 2, 4096, 65536, 0], "csrc_sha256": pkg.csrc_sha256(), "version": pkg.lib().alacgpu_version().decode(),
+import json as _j
+line = _j.load(open(os.path.join(out, "bench_under_rocprof.json")))
+wl = sys.argv[2].split()
+arg = lambda k, d: int(wl[wl.index(k) + 1]) if k in wl else d
+json.dump({"workload": [arg("--depth", 16), arg("--channels", 2), arg("--frame-length", 4096), arg("--packets", 65536), arg("--profile", 0)],
+           "bench_value": line.get("value"), "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"], "csrc_sha256": pkg.csrc_sha256(), "version": pkg.lib().alacgpu_version().decode(),
            "fetch_size_raw_bytes": fetch, "fetch_bytes_x2": 2 * fetch, "write_bytes": write,
            "traffic_bytes_per_launch": int(2 * fetch + write),
            "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, summed over the kernels of one decode; FETCH_SIZE doubled "

@@ -55,7 +55,7 @@ enum { ROLE_A = 0, ROLE_B = 1, ROLE_BOTH = 2 };
  * mode (per lane) != 0: the delta pre-pass of decoder.go:307-309 runs on the residual stream first (split
  * pipeline only: regular packets have mode 0).
  */
-template <class W, class B, int NA, int OUT, int ROLE, bool F16, bool NARROW, bool EA>
+template <class W, class B, int NA, int OUT, int ROLE, bool F16, bool NARROW, bool EA, bool UN8W = false>
 ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
                         uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
                         uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb, uint32_t mode) {
@@ -235,10 +235,13 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
      * asks for its U samples at the top of its own group: one dword per frame, first needed a whole step later, and
      * the extra registers and moves of looking ahead cost it more than the wait (2.45 -> 2.62 ms). */
 #ifndef ALAC_DUO_UN8_WIDE_MAX
-#define ALAC_DUO_UN8_WIDE_MAX 0 /* same for the wide writers (their groups also hold 64-bit shift windows) */
+#define ALAC_DUO_UN8_WIDE_MAX 0 /* same for the writers of the wider samples (generic: their groups also hold 64-bit shift windows) */
 #endif
+    /* UN8W: the caller's streams have 3-byte samples, whose writer (PK3 below) holds no 64-bit windows: groups of eight
+     * for predictors of up to eight taps. What it asks for a group ahead (shift bytes, U samples: scattered 64-byte
+     * reads from HBM) then has eight steps to arrive instead of four. */
     constexpr uint32_t UN = (NARROW && (((F16 || !LAST || RAW || EMIT_A) && NR <= ALAC_DUO_UN8_MAX) ||
-                                        NR <= ALAC_DUO_UN8_WIDE_MAX)) ? 8u : 4u;
+                                        NR <= (UN8W ? 8 : ALAC_DUO_UN8_WIDE_MAX))) ? 8u : 4u;
     constexpr bool HBM_IN = LAST && !RAW && !EMIT_A; /* the writer runs here and reads the U tile / shift bytes */
     /* role B fed from memory (split pipeline's predictor pass: W::kResMem): the residuals of a group are requested one
      * group ahead, like the U samples of the wide writers */
@@ -255,12 +258,13 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
      * instead of 64-bit shifts, three byte permutes per two frames instead of the generic packer's selects
      * (BASELINE config c). All live lanes must agree on the shift width (a wave of 24-bit packets with bytesShifted 2
      * among them takes the generic writer). */
-    constexpr bool PK3 = CPE && LAST && !F16 && !RAW && !EMIT_A && UN == 4u;
+    constexpr bool PK3 = CPE && LAST && !F16 && !RAW && !EMIT_A;
+    constexpr uint32_t NSUB = UN / 4u; /* blocks of four frames in a group */
     const bool sb8 = PK3 && !wv.any(ns != 0u && sb != 8u);
     const bool sb0 = PK3 && !wv.any(ns != 0u && sb != 0u);
     const bool pk3 = PK3 && bps == 3u && (sb8 || sb0);
     const uint32_t sh_byte = shift_pos >> 3, sh_bit = shift_pos & 7u;
-    uint32_t gpre0 = 0, gpre1 = 0, gpre2 = 0;
+    uint32_t gpre[NSUB][3] = {};
     const uint32_t sstep_b = (CPE ? 2u : 1u) * sb;
     const uint32_t steady_end = (n_it / CH) * CH; /* whole chunks end here */
     auto prefetch_group = [&](uint32_t row0) {
@@ -272,7 +276,10 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             if (CPE) upre[j] = *wv.u_row(row0 + j);
             if (merge_any && !pk3) spre[j] = bits.window_raw(shift_pos + (row0 + j) * sstep_b);
         }
-        if (PK3 && pk3 && sb8) bits.load12(sh_byte + 2u * row0, gpre0, gpre1, gpre2);
+        if (PK3 && pk3 && sb8) {
+#pragma unroll
+            for (uint32_t q = 0; q < NSUB; ++q) bits.load12(sh_byte + 2u * (row0 + 4u * q), gpre[q][0], gpre[q][1], gpre[q][2]);
+        }
     };
     /* B: samples of chunk c (UnpcBlock, predictor.go:45-684): out[0] = residual, warm-up up to na (:53-79),
      * copy (0) / delta (31) modes, then the adaptive taps */
@@ -303,7 +310,13 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
                         sv[j] = AHEAD ? spre[j] : 0ull;
                         if (HBM_IN && !AHEAD && CPE) uv[j] = *wv.u_row(row0 + j);
                     }
-                    const uint32_t g0 = gpre0, g1 = gpre1, g2 = gpre2;
+                    uint32_t gq[NSUB][3];
+#pragma unroll
+                    for (uint32_t q = 0; q < NSUB; ++q) {
+                        gq[q][0] = gpre[q][0];
+                        gq[q][1] = gpre[q][1];
+                        gq[q][2] = gpre[q][2];
+                    }
                     if (AHEAD && row0 + 2u * UN <= steady_end) prefetch_group(row0 + UN);
                     if (RMEM && row0 + 2u * UN <= steady_end) { /* rq_read indexes from the chunk's first step */
                         dpre_row = row0 + UN;
@@ -311,50 +324,54 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
                         for (uint32_t j = 0; j < UN; ++j) dpre[j] = wv.rq_read(buf, g + UN + j);
                     }
                     if (PK3 && pk3) {
-                        /* the eight shift bytes of the group: stream bits sh_bit .. sh_bit + 64 of the 12 bytes fetched */
-                        const uint32_t w0 = (uint32_t)(((((uint64_t)g0) << 32) | g1) << sh_bit >> 32);
-                        const uint32_t w1 = (uint32_t)(((((uint64_t)g1) << 32) | g2) << sh_bit >> 32);
-                        uint32_t lq[4], rq[4];
 #pragma unroll
-                        for (uint32_t j = 0; j < 4u; ++j) {
-                            const int32_t vv = predict(dv[j], wrap);
+                        for (uint32_t q = 0; q < NSUB; ++q) {
+                            /* the eight shift bytes of the block: stream bits sh_bit .. sh_bit + 64 of the 12 bytes fetched */
+                            const uint32_t g0 = gq[q][0], g1 = gq[q][1], g2 = gq[q][2];
+                            const uint32_t w0 = (uint32_t)(((((uint64_t)g0) << 32) | g1) << sh_bit >> 32);
+                            const uint32_t w1 = (uint32_t)(((((uint64_t)g1) << 32) | g2) << sh_bit >> 32);
+                            uint32_t lq[4], rq[4];
 #pragma unroll
-                            for (int t = NR; t >= 1; --t) hb[t] = hb[t - 1];
-                            hb[0] = (uint32_t)vv ^ BIAS;
-                            /* matrix.go:40-41 / :50-51, as in emit() */
-                            const int32_t mv = NARROW ? ALAC_MUL24(mix_res, vv) : (int32_t)((uint32_t)mix_res * (uint32_t)vv);
-                            int32_t l = uv[j] + (int32_t)((uint32_t)vv & nzm) - (mv >> mix_sh);
-                            int32_t r = (int32_t)((((uint32_t)(l - vv)) & nzm) | ((uint32_t)vv & ~nzm));
-                            if (sb8) { /* matrix.go:129-132 */
-                                const uint32_t w = j < 2u ? w0 : w1;
-                                const uint32_t sl = (j & 1u) ? (w >> 8) & 0xffu : w >> 24;
-                                const uint32_t sr = (j & 1u) ? w & 0xffu : (w >> 16) & 0xffu;
-                                l = (int32_t)(((uint32_t)l << 8) | sl);
-                                r = (int32_t)(((uint32_t)r << 8) | sr);
-                            } else if (cfg.bit_depth == 20) { /* matrix.go:77-78 */
-                                l = (int32_t)((uint32_t)l << 4);
-                                r = (int32_t)((uint32_t)r << 4);
+                            for (uint32_t j = 0; j < 4u; ++j) {
+                                const int32_t vv = predict(dv[4u * q + j], wrap);
+#pragma unroll
+                                for (int t = NR; t >= 1; --t) hb[t] = hb[t - 1];
+                                hb[0] = (uint32_t)vv ^ BIAS;
+                                /* matrix.go:40-41 / :50-51, as in emit() */
+                                const int32_t mv = NARROW ? ALAC_MUL24(mix_res, vv) : (int32_t)((uint32_t)mix_res * (uint32_t)vv);
+                                int32_t l = uv[4u * q + j] + (int32_t)((uint32_t)vv & nzm) - (mv >> mix_sh);
+                                int32_t r = (int32_t)((((uint32_t)(l - vv)) & nzm) | ((uint32_t)vv & ~nzm));
+                                if (sb8) { /* matrix.go:129-132 */
+                                    const uint32_t w = j < 2u ? w0 : w1;
+                                    const uint32_t sl = (j & 1u) ? (w >> 8) & 0xffu : w >> 24;
+                                    const uint32_t sr = (j & 1u) ? w & 0xffu : (w >> 16) & 0xffu;
+                                    l = (int32_t)(((uint32_t)l << 8) | sl);
+                                    r = (int32_t)(((uint32_t)r << 8) | sr);
+                                } else if (cfg.bit_depth == 20) { /* matrix.go:77-78 */
+                                    l = (int32_t)((uint32_t)l << 4);
+                                    r = (int32_t)((uint32_t)r << 4);
+                                }
+                                lq[j] = (uint32_t)l;
+                                rq[j] = (uint32_t)r;
                             }
-                            lq[j] = (uint32_t)l;
-                            rq[j] = (uint32_t)r;
+                            /* L0 L0 L0 R0 | R0 R0 L1 L1 | L1 R1 R1 R1, twice */
+                            const uint32_t d0 = (lq[0] & 0xffffffu) | (rq[0] << 24);
+                            const uint32_t d1 = ((rq[0] >> 8) & 0xffffu) | (lq[1] << 16);
+                            const uint32_t d2 = ((lq[1] >> 16) & 0xffu) | (rq[1] << 8);
+                            const uint32_t d3 = (lq[2] & 0xffffffu) | (rq[2] << 24);
+                            const uint32_t d4 = ((rq[2] >> 8) & 0xffffu) | (lq[3] << 16);
+                            const uint32_t d5 = ((lq[3] >> 16) & 0xffu) | (rq[3] << 8);
+                            /* a lane whose frames end inside the block (a partial frame) keeps the whole dwords of its
+                             * 6, 12 or 18 bytes; an odd count leaves two bytes for st_tail, as the generic packer would */
+                            const uint32_t nv = umin(ALAC_SUBSAT(ns, row0 + 4u * q), 4u);
+                            const uint32_t nby = nv * 6u;
+                            wv.st_push6_n(d0, d1, d2, d3, d4, d5, nby >> 2);
+                            if (nby & 2u) {
+                                pk_acc = (nv == 1u ? d1 : d4) & 0xffffu;
+                                pk_n = 2u;
+                            }
+                            wv.st_step();
                         }
-                        /* L0 L0 L0 R0 | R0 R0 L1 L1 | L1 R1 R1 R1, twice */
-                        const uint32_t d0 = (lq[0] & 0xffffffu) | (rq[0] << 24);
-                        const uint32_t d1 = ((rq[0] >> 8) & 0xffffu) | (lq[1] << 16);
-                        const uint32_t d2 = ((lq[1] >> 16) & 0xffu) | (rq[1] << 8);
-                        const uint32_t d3 = (lq[2] & 0xffffffu) | (rq[2] << 24);
-                        const uint32_t d4 = ((rq[2] >> 8) & 0xffffu) | (lq[3] << 16);
-                        const uint32_t d5 = ((lq[3] >> 16) & 0xffu) | (rq[3] << 8);
-                        /* a lane whose frames end inside the group (a partial frame) keeps the whole dwords of its
-                         * 6, 12 or 18 bytes; an odd count leaves two bytes for st_tail, as the generic packer would */
-                        const uint32_t nv = umin(ALAC_SUBSAT(ns, row0), 4u);
-                        const uint32_t nby = nv * 6u;
-                        wv.st_push6_n(d0, d1, d2, d3, d4, d5, nby >> 2);
-                        if (nby & 2u) {
-                            pk_acc = (nv == 1u ? d1 : d4) & 0xffffu;
-                            pk_n = 2u;
-                        }
-                        wv.st_step();
                         continue;
                     }
 #pragma unroll
@@ -429,13 +446,13 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
 ALAC_DEV constexpr bool duo_emit_in_a(uint32_t na, bool cpe) { return !cpe && na >= 5u && na <= 16u; }
 
 /* the order switch is scalar: NA is wave-uniform by construction of the waves. Role A never looks at the order. */
-template <class W, int OUT, int ROLE, bool F16, bool NARROW = true, class B>
+template <class W, int OUT, int ROLE, bool F16, bool NARROW = true, bool UN8W = false, class B>
 ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits, RegLane<W>& s, uint32_t size,
                            uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
                            int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb, uint32_t mode = 0u) {
 #define ALAC_DUO_CASE(N)                                                                                              \
     case N:                                                                                                           \
-        duo_phase<W, B, N, OUT, ROLE, F16, NARROW, CAN_EA && duo_emit_in_a(N, OUT == OUT_STEREO)>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, \
+        duo_phase<W, B, N, OUT, ROLE, F16, NARROW, CAN_EA && duo_emit_in_a(N, OUT == OUT_STEREO), UN8W>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, \
                                                                        den_shift, chan_bits, mix_res, mix_sh, na,     \
                                                                        shift_pos, sb, mode);                          \
         break;
@@ -557,7 +574,7 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
             if constexpr (DEPTH_SEL == 0 || DEPTH_SEL == 16) if (cfg.bit_depth == 16)
                 duo_phase_na<W, OUT_STEREO, ROLE, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
             if constexpr (DEPTH_SEL != 16) if (cfg.bit_depth != 16)
-                duo_phase_na<W, OUT_STEREO, ROLE, false>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+                duo_phase_na<W, OUT_STEREO, ROLE, false, true, DEPTH_SEL == 24>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
         }
         if (err_u == 0 && s.err != 0) err_chan = 1;
     }

@@ -143,8 +143,13 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
             const uint32_t key = alac::classify_regular(dc, p, sizes[i], avail);
             if (key != alac::KEY_IRREGULAR) {
                 if (classes_out) classes_out[i] = key;
-                status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH>(wv, dc, key, true, p, sizes[i], avail, o,
-                                                                                &frames_out[i]);
+                /* the same instantiations as the GPU library's kernels, one per sample width (k_dec16 / 24 / 32.hip) */
+                if (dc.bit_depth == 16)
+                    status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH, -1, 16>(wv, dc, key, true, p, sizes[i], avail, o, &frames_out[i]);
+                else if (dc.bit_depth == 32)
+                    status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH, -1, 32>(wv, dc, key, true, p, sizes[i], avail, o, &frames_out[i]);
+                else
+                    status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH, -1, 24>(wv, dc, key, true, p, sizes[i], avail, o, &frames_out[i]);
                 continue;
             }
         }
