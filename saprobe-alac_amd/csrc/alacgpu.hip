@@ -398,7 +398,8 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
                                (const alac::ChanDesc*)dec->cd.p, (int32_t*)dec->rows.p, rs, ppw2);
         }
         /* PCM of the split packets (with one or two channels: of the escape-only packets) */
-        const uint32_t ib = (uint32_t)std::min<uint64_t>((uint64_t)n * bpp, 8192u * (256u / il_threads));
+        /* a block takes eight slices of a packet at a time (k_split.hip: kSlices) */
+        const uint32_t ib = (uint32_t)std::min<uint64_t>((uint64_t)n * ((bpp + 7u) / 8u), 8192u * (256u / il_threads));
         hipLaunchKernelGGL(alac_interleave, dim3(ib), dim3(il_threads), 32u * il_threads, dec->stream, c, d_blob, blob_bytes, d_offsets, sz,
                            (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::ChanDesc*)dec->cd.p,
                            (const alac::PktDesc*)dec->pd.p, (const int32_t*)dec->rows.p, rs, d_out, (uint64_t)out_stride, bpp);

@@ -47,9 +47,14 @@ alac_chan_predict(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t b
     alac::decode_channel_task<GpuWaveMem, alac::ROLE_B>(wv, cfg, ukey, live, p, size, avail, d, row);
 }
 
+/* the slice buffer changes hands between the threads of a block: LDS traffic only. __syncthreads() would also wait for
+ * the global stores of the slice just written, and the loads of the next slice could not start before they are done */
+static __device__ __forceinline__ void il_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 /* one thread per (packet, frame) of the split packets: PCM in frame order. Blocks stride over the scanned
- * packets (the tail of the permutation that belongs to kKeyScan) x 256-frame slices. A slice is assembled in LDS
- * (a frame is 1..32 bytes at a byte offset of its own) and copied out as 16-byte pieces, whole lines at a time. */
+ * packets (the tail of the permutation that belongs to kKeyScan) x chunks of eight blockDim.x-frame slices. A slice is
+ * assembled in LDS (a frame is 1..32 bytes at a byte offset of its own) and copied out as 16-byte pieces, whole lines
+ * at a time. */
 __global__ void __launch_bounds__(256)
 alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
                 const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
@@ -58,14 +63,20 @@ alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blo
     extern __shared__ __attribute__((aligned(16))) uint8_t s_slice[]; /* blockDim.x frames of <= 32 bytes (launch: 32 * blockDim.x) */
     const uint32_t n_scan = plan->count[kKeyScan];
     const uint32_t first = plan->pkt_start[kKeyScan];
-    const uint64_t items = (uint64_t)n_scan * blocks_per_pkt;
     const uint32_t fb = cfg.num_channels * cfg.bps;
-    for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
-        const uint32_t pkt = perm[first + (uint32_t)(it / blocks_per_pkt)];
+    /* a block takes kSlices consecutive slices of one packet at a time: the packet's descriptors (a chain of dependent
+     * scalar loads: permutation -> descriptor -> offsets) are fetched once for them */
+    constexpr uint32_t kSlices = 8;
+    const uint32_t chunks_per_pkt = (blocks_per_pkt + kSlices - 1u) / kSlices;
+    const uint64_t chunks = (uint64_t)n_scan * chunks_per_pkt;
+    for (uint64_t ck = blockIdx.x; ck < chunks; ck += gridDim.x) {
+        const uint32_t pkt = perm[first + (uint32_t)(ck / chunks_per_pkt)];
         const alac::PktDesc& q = pd[pkt]; /* read in place: a copy indexed by slot would live in scratch memory */
         if (q.status != 0 || q.route != alac::ROUTE_SPLIT) continue; /* block-uniform */
-        const uint32_t f0 = (uint32_t)(it % blocks_per_pkt) * blockDim.x;
-        if (f0 >= q.frames) continue;
+        const uint32_t s0 = (uint32_t)(ck % chunks_per_pkt) * kSlices;
+      for (uint32_t sl = s0; sl < s0 + kSlices && sl < blocks_per_pkt; ++sl) {
+        const uint32_t f0 = sl * blockDim.x;
+        if (f0 >= q.frames) break;
         const uint32_t nf = min(q.frames - f0, (uint32_t)blockDim.x);
         const uint32_t f = f0 + threadIdx.x;
         if (threadIdx.x < nf) {
@@ -90,7 +101,7 @@ alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blo
             }
 #undef ALAC_IL_CASE
         }
-        __syncthreads();
+        il_sync();
         uint8_t* dst = out + (size_t)pkt * out_stride + (size_t)f0 * fb; /* f0 is a multiple of 64: 16-byte aligned */
         const uint32_t total = nf * fb;
         if (cfg.aligned16) {
@@ -100,7 +111,8 @@ alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blo
         } else {
             for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) dst[k] = s_slice[k];
         }
-        __syncthreads();
+        il_sync();
+      }
     }
 }
 
