@@ -5,10 +5,11 @@
 set -u
 OUT=$1; mkdir -p "$OUT/lines" "$OUT/placement"
 say() { echo "$(date +%T) $*" | tee -a "$OUT/progress.txt"; }
-say "bench (default flags)"
-python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || say "bench failed"
 say "collect_round"
 bash profiles/collect_round.sh "$OUT" > "$OUT/collect.log" 2>&1 || say "collect_round failed"
+say "bench (default flags; quotes the PMC traffic just taken: bench.py reads profiles/r*/traffic.json when its stamp matches)"
+mkdir -p profiles/r02_final && cp "$OUT/traffic.json" profiles/r02_final/traffic.json
+python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || say "bench failed"
 say "lines"
 bash tools/r2_lines.sh "$OUT/lines" > "$OUT/lines.txt" 2>&1 || say "lines failed"
 say "file bench"
