@@ -128,13 +128,48 @@ ALAC_DEV void interleave_frame(const DevCfg& cfg, const uint8_t* pkt, uint32_t s
  * registers: slot s of an NC-channel stream always lands in output channel layout_offset(NC, s) (decoder.go:55-64),
  * so with the slots unrolled every byte position is a compile-time constant — no byte stores, no per-byte address
  * arithmetic. f[] receives the frame as little-endian dwords; channels nobody wrote stay zero (decoder.go:120,127). */
+/* what a frame of the split packets needs from memory: per bitstream channel slot the sample (or, for the first slot
+ * of a pair, both) and the 8-byte window on its shift values. Kept apart from the arithmetic so that alac_interleave
+ * can ask for the next slice's values before it stores the current one (k_split.hip). */
+template <int NC>
+struct IlLoaded {
+    int32_t a[NC], b[NC];
+    uint64_t w[NC];
+};
+
 template <int NC, int BPS>
-ALAC_DEV void interleave_frame_packed(const DevCfg& cfg, const uint8_t* pkt, uint32_t size, uint32_t avail, const PktDesc& pd,
-                                      const ChanDesc* cd, const int32_t* rows, size_t row_stride, uint32_t i,
-                                      uint32_t (&f)[NC * BPS / 4]) {
+ALAC_DEV void interleave_load(const DevCfg& cfg, const uint8_t* pkt, uint32_t size, uint32_t avail, const PktDesc& pd,
+                              const ChanDesc* cd, const int32_t* rows, size_t row_stride, uint32_t i, IlLoaded<NC>& L) {
+    const Bits bits{pkt, size, avail};
+#pragma unroll
+    for (int slot = 0; slot < NC; ++slot) {
+        L.a[slot] = L.b[slot] = 0;
+        L.w[slot] = 0;
+        if ((uint32_t)slot >= pd.nslots) continue;
+        const ChanDesc d = cd[slot];
+        if (!(d.info & CD_VALID) || (d.info & CD_SECOND) || i >= d.ns) continue;
+        const bool cpe = (d.info & CD_CPE) != 0, escape = (d.info & CD_ESCAPE) != 0;
+        const uint32_t nch_e = cpe ? 2u : 1u;
+        const uint32_t chan_bits = (d.info >> CD_CHANBITS_SHIFT) & 63u;
+        const uint32_t sb = (d.info >> CD_SB_SHIFT) & 31u;
+        if (escape) { /* decodeSCEEscape / decodeCPEEscape, decoder.go:326-345 / 507-535 */
+            const uint32_t cs = 32u - chan_bits;
+            L.a[slot] = sext_cs((int32_t)bits.get(d.hdr_pos + (i * nch_e) * chan_bits, chan_bits), cs);
+            if (cpe) L.b[slot] = sext_cs((int32_t)bits.get(d.hdr_pos + (i * nch_e + 1u) * chan_bits, chan_bits), cs);
+        } else {
+            L.a[slot] = rows[(size_t)slot * row_stride + i];
+            if (cpe && slot + 1 < NC) L.b[slot] = rows[(size_t)(slot + 1) * row_stride + i];
+        }
+        /* matrix.go:129-132, 266-268: both shift values of a frame lie side by side (decoder.go:492-502) */
+        if (sb) L.w[slot] = bits.window(d.shift_pos + i * nch_e * sb);
+    }
+}
+
+template <int NC, int BPS>
+ALAC_DEV void interleave_build(const DevCfg& cfg, const PktDesc& pd, const ChanDesc* cd, uint32_t i, const IlLoaded<NC>& L,
+                               uint32_t (&f)[NC * BPS / 4]) {
     static_assert((NC * BPS) % 4 == 0, "whole dwords only");
     constexpr uint32_t MASK = BPS == 4 ? 0xffffffffu : ((1u << (8 * (BPS & 3))) - 1u);
-    const Bits bits{pkt, size, avail};
 #pragma unroll
     for (int k = 0; k < NC * BPS / 4; ++k) f[k] = 0;
     /* later elements overwrite earlier ones where a (non-standard) element order makes them meet, as the reference's
@@ -171,19 +206,9 @@ ALAC_DEV void interleave_frame_packed(const DevCfg& cfg, const uint8_t* pkt, uin
         if ((uint32_t)slot >= pd.nslots) continue;
         const ChanDesc d = cd[slot];
         if (!(d.info & CD_VALID) || (d.info & CD_SECOND) || i >= d.ns) continue;
-        const bool cpe = (d.info & CD_CPE) != 0, escape = (d.info & CD_ESCAPE) != 0;
-        const uint32_t nch_e = cpe ? 2u : 1u;
-        const uint32_t chan_bits = (d.info >> CD_CHANBITS_SHIFT) & 63u;
+        const bool cpe = (d.info & CD_CPE) != 0;
         const uint32_t sb = (d.info >> CD_SB_SHIFT) & 31u;
-        int32_t a, b = 0;
-        if (escape) { /* decodeSCEEscape / decodeCPEEscape, decoder.go:326-345 / 507-535 */
-            const uint32_t cs = 32u - chan_bits;
-            a = sext_cs((int32_t)bits.get(d.hdr_pos + (i * nch_e) * chan_bits, chan_bits), cs);
-            if (cpe) b = sext_cs((int32_t)bits.get(d.hdr_pos + (i * nch_e + 1u) * chan_bits, chan_bits), cs);
-        } else {
-            a = rows[(size_t)slot * row_stride + i];
-            if (cpe && slot + 1 < NC) b = rows[(size_t)(slot + 1) * row_stride + i];
-        }
+        const int32_t a = L.a[slot], b = L.b[slot];
         int32_t l = a, r = 0;
         if (cpe) {
             const int32_t mix_res = (int32_t)(int8_t)(d.mix & 0xff);
@@ -199,14 +224,24 @@ ALAC_DEV void interleave_frame_packed(const DevCfg& cfg, const uint8_t* pkt, uin
             l = (int32_t)((uint32_t)l << 4);
             r = (int32_t)((uint32_t)r << 4);
         }
-        if (sb) { /* matrix.go:129-132, 266-268: both shift values of a frame lie side by side (decoder.go:492-502) */
-            const uint64_t w = bits.window(d.shift_pos + i * nch_e * sb);
+        if (sb) {
+            const uint64_t w = L.w[slot];
             l = (int32_t)((uint32_t)l << sb) | (int32_t)(uint32_t)(w >> (64u - sb));
             if (cpe) r = (int32_t)((uint32_t)r << sb) | (int32_t)(uint32_t)((w << sb) >> (64u - sb));
         }
         emit_at(out_chan, l);
         if (cpe) emit_at(out_chan + 1, r); /* R goes right behind L (matrix.go:31-32), whatever the layout says about the next slot */
     }
+}
+
+/* load + build in one go (the host simulation, and whoever has no use for the split) */
+template <int NC, int BPS>
+ALAC_DEV void interleave_frame_packed(const DevCfg& cfg, const uint8_t* pkt, uint32_t size, uint32_t avail, const PktDesc& pd,
+                                      const ChanDesc* cd, const int32_t* rows, size_t row_stride, uint32_t i,
+                                      uint32_t (&f)[NC * BPS / 4]) {
+    IlLoaded<NC> L;
+    interleave_load<NC, BPS>(cfg, pkt, size, avail, pd, cd, rows, row_stride, i, L);
+    interleave_build<NC, BPS>(cfg, pd, cd, i, L, f);
 }
 
 } /* namespace alac */

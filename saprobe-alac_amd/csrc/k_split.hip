@@ -51,6 +51,47 @@ alac_chan_predict(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t b
  * the global stores of the slice just written, and the loads of the next slice could not start before they are done */
 static __device__ __forceinline__ void il_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+/* LDS slice -> PCM slot: 16-byte pieces, whole lines at a time */
+static __device__ __forceinline__ void il_store(uint8_t* dst, const uint8_t* slice, uint32_t total, bool aligned16) {
+    if (aligned16) {
+        for (uint32_t k = threadIdx.x * 16u; k + 16u <= total; k += blockDim.x * 16u)
+            *reinterpret_cast<uint4*>(dst + k) = *reinterpret_cast<const uint4*>(slice + k);
+        for (uint32_t k = (total & ~15u) + threadIdx.x; k < total; k += blockDim.x) dst[k] = slice[k];
+    } else {
+        for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) dst[k] = slice[k];
+    }
+}
+
+/* slices [s0, s_end) of one packet whose frames are whole dwords (compile-time byte positions). What slice s + 1 needs
+ * from memory is asked for BEFORE slice s is stored: the memory counter of a wave retires in issue order, stores
+ * included, so loads issued behind the stores would only be usable once those stores have reached memory. */
+template <int NC, int BPS>
+static __device__ __forceinline__ void il_chunk(const alac::DevCfg& cfg, const uint8_t* pk, uint32_t psz, uint32_t pav,
+                                                const alac::PktDesc& q, const alac::ChanDesc* pcd, const int32_t* prow,
+                                                size_t row_stride, uint8_t* dst_pkt, uint32_t s0, uint32_t s_end, uint8_t* slice) {
+    constexpr uint32_t DW = NC * BPS / 4;
+    alac::IlLoaded<NC> L;
+    uint32_t f0 = s0 * blockDim.x;
+    if (f0 + threadIdx.x < q.frames) alac::interleave_load<NC, BPS>(cfg, pk, psz, pav, q, pcd, prow, row_stride, f0 + threadIdx.x, L);
+    for (uint32_t sl = s0; sl < s_end && f0 < q.frames; ++sl) {
+        const uint32_t nf = min(q.frames - f0, (uint32_t)blockDim.x);
+        if (threadIdx.x < nf) {
+            uint32_t fr[DW];
+            alac::interleave_build<NC, BPS>(cfg, q, pcd, f0 + threadIdx.x, L, fr);
+            uint32_t* dw = reinterpret_cast<uint32_t*>(slice) + threadIdx.x * DW;
+#pragma unroll
+            for (uint32_t k = 0; k < DW; ++k) dw[k] = fr[k];
+        }
+        il_sync();
+        const uint32_t fn = f0 + blockDim.x;
+        if (sl + 1u < s_end && fn + threadIdx.x < q.frames)
+            alac::interleave_load<NC, BPS>(cfg, pk, psz, pav, q, pcd, prow, row_stride, fn + threadIdx.x, L);
+        il_store(dst_pkt + (size_t)f0 * (NC * BPS), slice, nf * (NC * BPS), cfg.aligned16 != 0); /* f0 is a multiple of 64: 16-byte aligned */
+        il_sync();
+        f0 = fn;
+    }
+}
+
 /* one thread per (packet, frame) of the split packets: PCM in frame order. Blocks stride over the scanned
  * packets (the tail of the permutation that belongs to kKeyScan) x chunks of eight blockDim.x-frame slices. A slice is
  * assembled in LDS (a frame is 1..32 bytes at a byte offset of its own) and copied out as 16-byte pieces, whole lines
@@ -74,45 +115,32 @@ alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blo
         const alac::PktDesc& q = pd[pkt]; /* read in place: a copy indexed by slot would live in scratch memory */
         if (q.status != 0 || q.route != alac::ROUTE_SPLIT) continue; /* block-uniform */
         const uint32_t s0 = (uint32_t)(ck % chunks_per_pkt) * kSlices;
-      for (uint32_t sl = s0; sl < s0 + kSlices && sl < blocks_per_pkt; ++sl) {
-        const uint32_t f0 = sl * blockDim.x;
-        if (f0 >= q.frames) break;
-        const uint32_t nf = min(q.frames - f0, (uint32_t)blockDim.x);
-        const uint32_t f = f0 + threadIdx.x;
-        if (threadIdx.x < nf) {
-            const uint8_t* pk = blob + offsets[pkt];
-            const uint32_t psz = sizes[pkt], pav = avail_of(blob_bytes, offsets[pkt]);
-            const alac::ChanDesc* pcd = cd + (size_t)pkt * 8u;
-            const int32_t* prow = rows + (size_t)pkt * cfg.num_channels * row_stride;
-            /* frames of whole dwords are built in registers (compile-time byte positions) and stored as dwords */
-#define ALAC_IL_CASE(NC_, BPS_)                                                                                        \
-    case (NC_) * 8 + (BPS_): {                                                                                         \
-        uint32_t fr[(NC_) * (BPS_) / 4];                                                                               \
-        alac::interleave_frame_packed<NC_, BPS_>(cfg, pk, psz, pav, q, pcd, prow, (size_t)row_stride, f, fr);          \
-        uint32_t* dw = reinterpret_cast<uint32_t*>(s_slice) + threadIdx.x * ((NC_) * (BPS_) / 4);                      \
-        _Pragma("unroll") for (int k = 0; k < (NC_) * (BPS_) / 4; ++k) dw[k] = fr[k];                                  \
-        break;                                                                                                         \
-    }
-            switch (cfg.num_channels * 8u + cfg.bps) {
-                ALAC_IL_CASE(4, 2) ALAC_IL_CASE(6, 2) ALAC_IL_CASE(8, 2) ALAC_IL_CASE(4, 3) ALAC_IL_CASE(8, 3)
-                ALAC_IL_CASE(3, 4) ALAC_IL_CASE(4, 4) ALAC_IL_CASE(5, 4) ALAC_IL_CASE(6, 4) ALAC_IL_CASE(7, 4) ALAC_IL_CASE(8, 4)
-                default:
-                    alac::interleave_frame(cfg, pk, psz, pav, q, pcd, prow, (size_t)row_stride, f, s_slice + threadIdx.x * fb);
-            }
+        const uint8_t* pk = blob + offsets[pkt];
+        const uint32_t psz = sizes[pkt], pav = avail_of(blob_bytes, offsets[pkt]);
+        const alac::ChanDesc* pcd = cd + (size_t)pkt * 8u;
+        const int32_t* prow = rows + (size_t)pkt * cfg.num_channels * row_stride;
+        uint8_t* dst_pkt = out + (size_t)pkt * out_stride;
+        const uint32_t s_end = min(s0 + kSlices, blocks_per_pkt);
+#define ALAC_IL_CASE(NC_, BPS_)                                                                              \
+    case (NC_) * 8 + (BPS_):                                                                                 \
+        il_chunk<NC_, BPS_>(cfg, pk, psz, pav, q, pcd, prow, (size_t)row_stride, dst_pkt, s0, s_end, s_slice); \
+        break;
+        switch (cfg.num_channels * 8u + cfg.bps) {
+            ALAC_IL_CASE(4, 2) ALAC_IL_CASE(6, 2) ALAC_IL_CASE(8, 2) ALAC_IL_CASE(4, 3) ALAC_IL_CASE(8, 3)
+            ALAC_IL_CASE(3, 4) ALAC_IL_CASE(4, 4) ALAC_IL_CASE(5, 4) ALAC_IL_CASE(6, 4) ALAC_IL_CASE(7, 4) ALAC_IL_CASE(8, 4)
+            default: /* frames that are not whole dwords: byte by byte into the slice */
+                for (uint32_t sl = s0; sl < s_end; ++sl) {
+                    const uint32_t f0 = sl * blockDim.x;
+                    if (f0 >= q.frames) break;
+                    const uint32_t nf = min(q.frames - f0, (uint32_t)blockDim.x);
+                    if (threadIdx.x < nf)
+                        alac::interleave_frame(cfg, pk, psz, pav, q, pcd, prow, (size_t)row_stride, f0 + threadIdx.x, s_slice + threadIdx.x * fb);
+                    il_sync();
+                    il_store(dst_pkt + (size_t)f0 * fb, s_slice, nf * fb, cfg.aligned16 != 0);
+                    il_sync();
+                }
+        }
 #undef ALAC_IL_CASE
-        }
-        il_sync();
-        uint8_t* dst = out + (size_t)pkt * out_stride + (size_t)f0 * fb; /* f0 is a multiple of 64: 16-byte aligned */
-        const uint32_t total = nf * fb;
-        if (cfg.aligned16) {
-            for (uint32_t k = threadIdx.x * 16u; k + 16u <= total; k += blockDim.x * 16u)
-                *reinterpret_cast<uint4*>(dst + k) = *reinterpret_cast<const uint4*>(s_slice + k);
-            for (uint32_t k = (total & ~15u) + threadIdx.x; k < total; k += blockDim.x) dst[k] = s_slice[k];
-        } else {
-            for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) dst[k] = s_slice[k];
-        }
-        il_sync();
-      }
     }
 }
 
