@@ -63,6 +63,9 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     constexpr bool RAW = OUT == OUT_RAW;
     constexpr bool LAST = OUT == OUT_STEREO || OUT == OUT_MONO || RAW; /* B stages what it reconstructs */
     constexpr bool CPE = OUT == OUT_STEREO;
+    /* what role B reads: residuals through the LDS queue (the entropy wave has slack: it folds the sign, golomb.go:206-209),
+     * n + zmode as the scan left it in the rows of the split pipeline (a lone chain: every instruction counts there) */
+    constexpr bool QND = W::kResMem;
     constexpr bool GEN = NA == 0;
     /* GEN only ever serves orders 0 (copy) and 31 (delta): every order with taps has its own instantiation */
     constexpr int NR = GEN ? 1 : NA;
@@ -78,6 +81,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     ALAC_OWN_REG(kb); /* its own register: cfg is an 8-dword kernel-argument tuple that would otherwise be pulled out
                          of its spill slot, whole, in every step of the entropy loop (8 v_readlane per step) */
     const uint32_t wb = go_shl(1u, kb) - 1u; /* SetAGParams golomb.go:60: KB >= 32 gives all ones (KB is a cookie byte) */
+    const uint32_t c31kb = 31u - kb;         /* gol_step keeps k as 31 - k; as a signed number (KB may exceed 31) */
     const uint32_t chan_shift = 32u - chan_bits;
     const int32_t den_half = den_shift ? (int32_t)(1u << (den_shift - 1u)) : 0;
     const uint32_t rnd_neg = (1u << den_shift) - 1u;
@@ -112,23 +116,30 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
         if (NARROW) return predict_narrow<NR, GEN, WR, !RAW>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
         return predict_wide<NR, GEN, WR>(coef, hb, na, del, den_shift, den_half, chan_shift);
     };
+    /* the same from what the queue / the row holds */
+    auto predict_q = [&](int32_t x, auto wrap) -> int32_t {
+        constexpr bool WR = decltype(wrap)::value;
+        if (!QND) return predict(x, wrap);
+        if (NARROW) return predict_narrow_nd<NR, GEN, WR, !RAW>(coef, hb, na, (uint32_t)x, den_shift, den_half, rnd_neg, chan_shift);
+        return predict_wide<NR, GEN, WR>(coef, hb, na, gol_unfold((uint32_t)x), den_shift, den_half, chan_shift);
+    };
     using wrap_yes = std::integral_constant<bool, WRAP>;
     using wrap_no = std::integral_constant<bool, false>;
     const uint32_t nzm = mix_res != 0 ? 0xffffffffu : 0u; /* per lane: the pair is matrixed (matrix.go:34) */
 
-    /* A: residuals of chunk c (DynDecomp, golomb.go:167-247). Whole chunks run as two straight-line groups of four
-     * steps (the bitstream ring is topped up once per group, 4 steps ahead of need). */
+    /* A: residuals of chunk c (DynDecomp, golomb.go:167-247). Whole chunks run as straight-line groups of four steps (the bitstream ring is topped
+     * up once per group, 4 steps ahead of need). */
     uint32_t ns_live = s.err == 0 ? ns : 0u;
-    uint32_t on_mask = (uint32_t)((int32_t)(0u - ns_live) >> 31); /* 0 < ns_live */
     auto golomb_chunk = [&](uint32_t c) {
         const uint32_t buf = c & 1u;
         if ((c + 1u) * CH <= n_it) {
 #pragma nounroll
             for (uint32_t g = 0; g < CH; g += 4u) {
                 s.rd.tick(wv);
+                s.near = gol_near(s, c * CH + g, ns_live);
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; ++j)
-                    wv.rq_write(buf, g + j, gol_step(wv, bits, s, size, kb, wb, chan_bits, c * CH + g + j, ns, ns_live, on_mask));
+                    wv.rq_write(buf, g + j, gol_unfold(gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, c * CH + g + j, ns, ns_live)));
             }
             return;
         }
@@ -136,13 +147,23 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
         for (uint32_t j = 0; j < CH; ++j) {
             const uint32_t i = c * CH + j;
             if (i >= n_it) break;
-            if ((i & 3u) == 0) s.rd.tick(wv);
-            wv.rq_write(buf, j, gol_step(wv, bits, s, size, kb, wb, chan_bits, i, ns, ns_live, on_mask));
+            if ((i & 3u) == 0) {
+                s.rd.tick(wv);
+                s.near = gol_near(s, i, ns_live);
+            }
+            wv.rq_write(buf, j, gol_unfold(gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i, ns, ns_live)));
         }
     };
     /* PCM of frame i from its last channel's sample o (unmix / shift merge / packing / stager).
      * u: the U sample of frame i (pairs), sw: window on the frame's shift values (24/32-bit) */
-    auto emit = [&](uint32_t i, int32_t o, int32_t u, uint64_t sw) {
+    /* FP_OK / fp: 16-bit pairs in chunks that every lane keeps whole or not at all: the writer pushes a group's dwords at
+     * fixed places and counts them once (GpuWave::st_put), instead of testing and counting per step */
+    constexpr bool FP_OK = F16 && CPE && LAST && !EMIT_A && !RAW;
+    uint32_t fp_base = 0, fp_inc = 0;
+    using fp_yes = std::integral_constant<bool, true>;
+    using fp_no = std::integral_constant<bool, false>;
+    auto emit = [&](uint32_t i, int32_t o, int32_t u, uint64_t sw, uint32_t jj, auto fp) {
+        constexpr bool FP = decltype(fp)::value;
         const bool on = i < ns;
         if (RAW) {
             wv.st_push_if((uint32_t)o, on); /* one int32 sample per step into the lane's row */
@@ -158,7 +179,9 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             r = (int32_t)((((uint32_t)(l - vv)) & nzm) | ((uint32_t)vv & ~nzm));
         }
         if (F16) {
-            wv.st_push_if(((uint32_t)l & 0xffffu) | ((uint32_t)r << 16), on);
+            const uint32_t pcm = ((uint32_t)l & 0xffffu) | ((uint32_t)r << 16);
+            if (FP) wv.st_put(fp_base, jj, pcm, fp_inc);
+            else wv.st_push_if(pcm, on);
             return;
         }
         if (cfg.bit_depth == 20) { /* matrix.go:77-78, 237 */
@@ -193,13 +216,16 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     };
     /* B: sample i (step j of chunk buffer buf) is reconstructed: history; then the U hand-off tile, the sample
      * queue to wave A, or the writer */
-    auto put = [&](uint32_t buf, uint32_t j, uint32_t i, int32_t o, int32_t u, uint64_t sw) {
+    auto put = [&](uint32_t buf, uint32_t j, uint32_t i, int32_t o, int32_t u, uint64_t sw, uint32_t jj, auto fp) {
 #pragma unroll
         for (int t = NR; t >= 1; --t) hb[t] = hb[t - 1];
         hb[0] = (uint32_t)o ^ BIAS;
         if (!LAST) *wv.u_row(i) = o; /* dead lanes write their own unused cell */
-        else if (EMIT_A) wv.rq_write(buf, CH + j, o);
-        else emit(i, o, u, sw);
+        else if (EMIT_A) {
+            wv.rq_write(buf, CH + j, o);
+            if (CPE) wv.rq_write(buf, 2u * CH + j, u); /* the U sample rides along: wave A has no business with the tile */
+        }
+        else emit(i, o, u, sw, jj, fp);
     };
     /* A (EMIT_A): inputs of the chunk it writes, requested before the Golomb work of the iteration */
     int32_t sq_v[CH], u_v[CH];
@@ -215,7 +241,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             sw_v[j] = 0;
             if (i < n_it) { /* scalar: rows past n_it do not exist in the tile */
                 sq_v[j] = wv.rq_read(buf, CH + j);
-                if (CPE) u_v[j] = *wv.u_row(i);
+                if (CPE) u_v[j] = wv.rq_read(buf, 2u * CH + j);
                 if (merge_any) sw_v[j] = bits.window_raw(shift_pos + i * sstep_a);
             }
         }
@@ -224,7 +250,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
 #pragma unroll
         for (uint32_t j = 0; j < CH; ++j) {
             const uint32_t i = c * CH + j;
-            if (i < n_it) emit(i, sq_v[j], u_v[j], sw_v[j]);
+            if (i < n_it) emit(i, sq_v[j], u_v[j], sw_v[j], 0u, fp_no{});
         }
         wv.st_step(); /* collective of wave A */
     };
@@ -248,7 +274,10 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     constexpr bool RMEM = W::kResMem && ROLE == ROLE_B;
     int32_t dpre[UN];
     uint32_t dpre_row = 0xffffffffu;
-    constexpr bool AHEAD = HBM_IN && !F16;
+#ifndef ALAC_AHEAD_F16
+#define ALAC_AHEAD_F16 1
+#endif
+    constexpr bool AHEAD = HBM_IN && (!F16 || ALAC_AHEAD_F16 != 0);
     int32_t upre[UN];
     uint64_t spre[UN];
     uint32_t pre_row = 0xffffffffu; /* first frame of the group upre / spre hold */
@@ -292,10 +321,16 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             /* steady state, a whole chunk: straight-line code; residuals (LDS), U samples and shift values
              * (HBM/L2) are all requested up front and their latency hides behind the taps of the first steps;
              * the history shift becomes register renaming across the unrolled steps */
-            auto groups = [&](auto wrap) {
+            auto groups = [&](auto wrap, auto fp) {
+                constexpr bool FP = decltype(fp)::value;
+#if ALAC_AHEAD_F16 == 2
+#pragma unroll
+#else
 #pragma nounroll
+#endif
                 for (uint32_t g = 0; g < CH; g += UN) {
                     const uint32_t row0 = c * CH + g;
+                    if (FP) fp_base = wv.st_group_base(UN);
                     int32_t dv[UN], uv[UN];
                     uint64_t sv[UN];
                     if (AHEAD && pre_row != row0) prefetch_group(row0); /* first steady group: nothing was ahead */
@@ -308,7 +343,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
                         dv[j] = RMEM ? dpre[j] : wv.rq_read(buf, g + j);
                         uv[j] = AHEAD ? upre[j] : 0;
                         sv[j] = AHEAD ? spre[j] : 0ull;
-                        if (HBM_IN && !AHEAD && CPE) uv[j] = *wv.u_row(row0 + j);
+                        if ((HBM_IN || EMIT_A) && !AHEAD && CPE) uv[j] = *wv.u_row(row0 + j);
                     }
                     uint32_t gq[NSUB][3];
 #pragma unroll
@@ -333,7 +368,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
                             uint32_t lq[4], rq[4];
 #pragma unroll
                             for (uint32_t j = 0; j < 4u; ++j) {
-                                const int32_t vv = predict(dv[4u * q + j], wrap);
+                                const int32_t vv = predict_q(dv[4u * q + j], wrap);
 #pragma unroll
                                 for (int t = NR; t >= 1; --t) hb[t] = hb[t - 1];
                                 hb[0] = (uint32_t)vv ^ BIAS;
@@ -376,11 +411,29 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
                     }
 #pragma unroll
                     for (uint32_t j = 0; j < UN; ++j)
-                        put(buf, g + j, c * CH + g + j, predict(dv[j], wrap), uv[j], sv[j]);
+                        put(buf, g + j, c * CH + g + j, predict_q(dv[j], wrap), uv[j], sv[j], j, fp);
+                    if (FP) wv.st_advance(fp_inc);
                     /* collective of the writing wave, once per group: a lane row holds 64 dwords, a flush takes
                      * 32, and a group adds at most 8 steps x 2 dwords */
                     if (LAST && !EMIT_A) wv.st_step();
                 }
+            };
+            /* the writer's short cut (FP_OK above) when no lane's frames end strictly inside this chunk; a lane whose
+             * frames do writes its tail out right behind the chunk, for the short cut scribbles over finished rows */
+            auto run_groups = [&](auto wrap) {
+                if (FP_OK) {
+                    const uint32_t c_end = (c + 1u) * CH;
+                    const bool ends_here = ns > c * CH && ns < c_end;
+                    if (!wv.any(ends_here)) {
+                        fp_inc = ns >= c_end ? UN : 0u;
+                        groups(wrap, fp_yes{});
+                        return;
+                    }
+                    groups(wrap, fp_no{});
+                    if (ends_here) (void)wv.st_finish();
+                    return;
+                }
+                groups(wrap, fp_no{});
             };
             if (WRAP) {
                 /* A coefficient moves by at most 1 per step, so one that is further than a chunk away from the
@@ -391,25 +444,27 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
 #pragma unroll
                 for (int j = 0; j < NR; ++j) far = umax(far, (uint32_t)coef[j] + T);
                 if (!wv.any(far > 2u * T)) {
-                    groups(wrap_no{});
+                    run_groups(wrap_no{});
                     return;
                 }
             }
-            groups(wrap_yes{});
+            run_groups(wrap_yes{});
             return;
         }
 #pragma nounroll
         for (uint32_t j = 0; j < CH; ++j) {
             const uint32_t i = c * CH + j;
             if (i >= n_it) break;
-            const int32_t del = prepass(i, wv.rq_read(buf, j));
+            const int32_t qv = wv.rq_read(buf, j);
+            const int32_t del = prepass(i, QND ? gol_unfold((uint32_t)qv) : qv);
             int32_t o;
             if (i == 0 || (GEN && na == 0)) o = del;
             else if (i <= na || (GEN && na == 31)) o = sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
             else o = predict(del, wrap_yes{});
-            put(buf, j, i, o, (CPE && !EMIT_A) ? *wv.u_row(i) : 0,
-                (!EMIT_A && merge_any) ? bits.window_raw(shift_pos + i * sstep) : 0ull);
+            put(buf, j, i, o, CPE ? *wv.u_row(i) : 0,
+                (!EMIT_A && merge_any) ? bits.window_raw(shift_pos + i * sstep) : 0ull, 0u, fp_no{});
             if (LAST && !EMIT_A) wv.st_step();
+            if (FP_OK && i + 1u == ns) (void)wv.st_finish(); /* see run_groups */
         }
     };
 
@@ -417,6 +472,9 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
      * c-2 from the samples B queued in iteration c-1); the barrier publishes the buffers written in the iteration */
     const uint32_t nch = (n_it + CH - 1u) / CH;
     const uint32_t iters = nch + (EMIT_A ? 2u : 1u);
+#ifdef ALAC_DUO_PROF
+    constexpr uint32_t kProfPhase = LAST ? 4u : 0u; /* ALAC_DUO_STAMP: the U phase and the last phase apart */
+#endif
     for (uint32_t c = 0; c < iters; ++c) {
         ALAC_DUO_STAMP(0);
         if (DO_A) {
@@ -443,7 +501,15 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
  * does not; for single channels the writer balances the pair better in A from order 5 on (mono 16-bit: 1.93 ->
  * 1.63 ms). Not for pairs: the writer then needs the U tile and the shift bytes from HBM, and in wave A every wait
  * for the bitstream ring (vmcnt counts in order) would also wait for those loads (measured: 3.15 -> 3.55 ms). */
-ALAC_DEV constexpr bool duo_emit_in_a(uint32_t na, bool cpe) { return !cpe && na >= 5u && na <= 16u; }
+/* Round 3: the entropy step lost a third of its instructions (gol_step), so the writer of 16-bit pairs moved over too:
+ * the predictor wave hands wave A the V sample AND the U sample it has loaded from the tile, both through the LDS queue,
+ * so wave A still waits on nothing but its bitstream ring. */
+#ifndef ALAC_EA_CPE_MIN
+#define ALAC_EA_CPE_MIN 99
+#endif
+ALAC_DEV constexpr bool duo_emit_in_a(uint32_t na, bool cpe, bool f16) {
+    return cpe ? (f16 && na >= (uint32_t)ALAC_EA_CPE_MIN && na <= 16u) : (na >= 5u && na <= 16u);
+}
 
 /* the order switch is scalar: NA is wave-uniform by construction of the waves. Role A never looks at the order. */
 template <class W, int OUT, int ROLE, bool F16, bool NARROW = true, bool UN8W = false, class B>
@@ -452,13 +518,13 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits,
                            int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb, uint32_t mode = 0u) {
 #define ALAC_DUO_CASE(N)                                                                                              \
     case N:                                                                                                           \
-        duo_phase<W, B, N, OUT, ROLE, F16, NARROW, CAN_EA && duo_emit_in_a(N, OUT == OUT_STEREO), UN8W>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, \
+        duo_phase<W, B, N, OUT, ROLE, F16, NARROW, CAN_EA && duo_emit_in_a(N, OUT == OUT_STEREO, F16), UN8W>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, \
                                                                        den_shift, chan_bits, mix_res, mix_sh, na,     \
                                                                        shift_pos, sb, mode);                          \
         break;
     constexpr bool CAN_EA = NARROW && (OUT == OUT_STEREO || OUT == OUT_MONO); /* phases that write PCM; not the wide ones */
     if (ROLE == ROLE_A) {
-        if (CAN_EA && duo_emit_in_a(na, OUT == OUT_STEREO))
+        if (CAN_EA && duo_emit_in_a(na, OUT == OUT_STEREO, F16))
             duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, true>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
                                                           mix_res, mix_sh, na, shift_pos, sb, mode);
         else
@@ -511,7 +577,8 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     RegLane<W> s;
     s.rd.init(pkt, size);
     s.err = 0;
-    s.max_pos = size * 8u;
+    s.near = 0;
+    s.max_pos = size * 8u + s.rd.bias; /* positions of the lane state are biased (RingRd) */
 
     /* header (accepted by classify_regular, so no error can arise here): decoder.go:213-235, 421-450 */
     uint32_t pos = 23;
@@ -532,13 +599,13 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     const uint32_t hv = bits.get(hdr_v, 16);
     const uint32_t bs = (bits.get(19, 4) >> 1) & 3u;
     const uint32_t shift_pos = cpe ? hdr_v + 16u + 16u * na_v : hdr_v; /* decoder.go:289-293, 453-457 */
-    s.pos = shift_pos + bs * 8u * (cpe ? 2u : 1u) * ns;
+    s.pos = shift_pos + bs * 8u * (cpe ? 2u : 1u) * ns + s.rd.bias;
     const uint32_t chan_bits = cfg.bit_depth - 8u * bs + (cpe ? 1u : 0u);
     /* the 16- and 20-bit writers ignore the shift buffer (matrix.go:30,66) */
     const uint32_t sb = (cfg.bit_depth == 24 || cfg.bit_depth == 32) ? bs * 8u : 0u;
     const uint32_t n_it = wv.max_u32(ns);
     /* the stager belongs to the wave that writes the PCM of the last channel (duo_emit_in_a) */
-    const bool emit_a = !wide && duo_emit_in_a(cpe ? na_v : na_u, cpe);
+    const bool emit_a = !wide && duo_emit_in_a(cpe ? na_v : na_u, cpe, cfg.bit_depth == 16);
     const bool writer = emit_a ? DO_A : DO_B;
     if (writer && live) wv.st_begin(out);
 
@@ -547,7 +614,7 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     s.zmode = 0;
     s.zrem = 0;
     s.pb = (cfg.pb * ((hu >> 5) & 7u)) / 4u; /* decoder.go:299 */
-    if (DO_A) s.rd.start(wv, live ? s.pos : 0u);
+    if (DO_A) s.rd.start(wv, live ? s.pos : s.rd.bias);
     if constexpr (WIDE_SEL != 1) if (!wide) {
         if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
         else duo_phase_na<W, OUT_MONO, ROLE, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
@@ -560,13 +627,13 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     /* ---- V ---- */
     if (cpe) {
         const bool u_failed = s.err != 0;
-        if (!u_failed && ((s.pos >> 3) > size + 4u || (s.pos >> 3) > size)) s.err = ST_MALFORMED; /* DynDecomp entry */
+        if (!u_failed && ((s.upos() >> 3) > size + 4u || (s.upos() >> 3) > size)) s.err = ST_MALFORMED; /* DynDecomp entry */
         const int32_t err_u = s.err;
         s.mean = cfg.mb;
         s.zmode = 0;
         s.zrem = 0;
         s.pb = (cfg.pb * ((hv >> 5) & 7u)) / 4u;
-        if (DO_A) s.rd.start(wv, (live && s.err == 0) ? s.pos : 0u);
+        if (DO_A) s.rd.start(wv, (live && s.err == 0) ? s.pos : s.rd.bias);
         if constexpr (WIDE_SEL != 0) if (wide)
             duo_phase_na<W, OUT_STEREO, ROLE, false, false>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
         /* DEPTH_SEL 16 / 24 / 32: the caller's configuration has that sample width (24 stands for both 3-byte depths) */

@@ -23,6 +23,7 @@
 #include <vector>
 
 #define ALAC_DEV __device__ __forceinline__
+#define ALAC_HD __host__ __device__ __forceinline__
 #define ALAC_NOINLINE
 #define ALAC_MUL24(a, b) __mul24((int)(a), (int)(b))
 /* |a - b| + c in one instruction. As an expression (max - min + c) the compiler shares the max / min between the
@@ -71,6 +72,26 @@ __device__ __forceinline__ int32_t alac_msub24(int32_t acc, int32_t a, int32_t n
 }
 #define ALAC_MSUB24(acc, a, c) alac_msub24((int32_t)(acc), (int32_t)(a), -(int32_t)(c))
 #define ALAC_SUBSAT(a, b) __builtin_elementwise_sub_sat((uint32_t)(a), (uint32_t)(b))
+/* v_ffbh_u32 as it is: leading zeros, 2^32 - 1 for 0 */
+__device__ __forceinline__ uint32_t alac_ffbh(uint32_t x) {
+    uint32_t r;
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+#define ALAC_FFBH(x) alac_ffbh((uint32_t)(x))
+/* (x >> off[4:0]) & ((1 << width[4:0]) - 1) */
+__device__ __forceinline__ uint32_t alac_bfe(uint32_t x, uint32_t off, uint32_t width) {
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(off), "v"(width));
+    return r;
+}
+#define ALAC_BFE(x, off, width) alac_bfe((uint32_t)(x), (uint32_t)(off), (uint32_t)(width))
+__device__ __forceinline__ int32_t alac_sext_bits(int32_t x, uint32_t bits) {
+    int32_t r;
+    asm("v_bfe_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(bits));
+    return r;
+}
+#define ALAC_SEXT_BITS(x, bits) alac_sext_bits((int32_t)(x), (uint32_t)(bits))
 #define ALAC_MULU24(a, b) __umul24((unsigned)(a), (unsigned)(b))
 #define ALAC_PICK(dst, src) asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(src))
 #define ALAC_OWN_REG(x) asm volatile("" : "+v"(x))
@@ -86,12 +107,12 @@ typedef uint32_t alac_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef int32_t alac_i32x4 __attribute__((ext_vector_type(4)));
 #define ALAC_STORE4(q, a, b, c, d) (*reinterpret_cast<alac_i32x4*>(q) = alac_i32x4{(a), (b), (c), (d)})
 #ifdef ALAC_DUO_PROF
-/* profiling build: cycles (s_memtime) between the stamps of alac_duo.h, summed per role over all waves */
-static __device__ unsigned long long g_duo_prof[16];
+/* profiling build: cycles (s_memtime) between the stamps of alac_duo.h, summed per role over all waves into
+ * Plan::prof (the plan is zeroed before every decode; alacgpu_debug_prof reads the last one back) */
 #define ALAC_DUO_STAMP(k)                                                   \
     do {                                                                    \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
-        if ((k) > 0) wv.prof[(k) - 1] += t_ - wv.prof_t;                     \
+        if ((k) > 0) wv.prof[kProfPhase + (k) - 1] += t_ - wv.prof_t;         \
         wv.prof_t = t_;                                                     \
     } while (0)
 #endif
@@ -154,6 +175,9 @@ struct Plan {
     uint32_t gate[2][512];
     uint32_t balance[2][512]; /* per SIMD of the CU, a byte each: entropy waves - predictor waves placed there */
     uint32_t queue[2];
+#ifdef ALAC_DUO_PROF
+    unsigned long long prof[32]; /* [role A: U phase 0..3, last phase 4..7 | role B: 16..19, 20..23] */
+#endif
 };
 
 /* LDS of the decode kernel (one wave per workgroup). Referenced by name, never through a generic pointer, so
@@ -163,7 +187,10 @@ static __shared__ unsigned long long s_optr[kWave];                             
 static __shared__ __attribute__((aligned(16))) uint32_t s_ring[kWave * kRingStride];    /* bitstream rings */
 /* residual queue of the wave pair (alac_duo.h), A -> B, double-buffered chunks */
 constexpr uint32_t kQ = alac::DUO_CHUNK;
-static __shared__ int32_t s_rq[2 * kQ * kWave];
+/* rows per buffer: a chunk of residuals A -> B; where wave A writes the PCM (alac_duo.h: EMIT_A) half a chunk of
+ * residuals, half a chunk of samples B -> A and, for pairs, half a chunk of U samples B -> A */
+constexpr uint32_t kQRows = alac::DUO_CHUNK + alac::DUO_CHUNK / 2u;
+static __shared__ int32_t s_rq[2 * kQRows * kWave];
 
 /* U hand-off tile of one wave: frame_length rows of 64 cells and one spare row (the single-wave decoders read one
  * row ahead) */
@@ -173,13 +200,13 @@ __host__ __device__ inline size_t u_tile_cells(uint32_t frame_length) { return (
 struct GpuWave {
     static constexpr bool kResMem = false; /* residuals come through the LDS queue */
     static constexpr uint32_t kRingDw = alack::kRingDw;
-    int32_t* u_tile;           /* HBM: this lane's column of the wave's U hand-off tile */
+    int32_t* u_tile;           /* HBM: the wave's U hand-off tile (wave-uniform: rows are addressed scalar base + lane) */
     int32_t* g_tile;           /* HBM: this lane's column of the wave's fall-back tile */
     uint8_t* my_out;
     uint32_t lane, wcnt, flushed;
     uint32_t ppw;              /* packets (= live lanes) per wave; also the row stride of the HBM tiles */
 #ifdef ALAC_DUO_PROF
-    unsigned long long prof[4] = {0, 0, 0, 0}, prof_t = 0;
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = 0;
 #endif
 
     ALAC_DEV bool any(bool p) const { return __ballot(p) != 0ull; }
@@ -206,6 +233,14 @@ struct GpuWave {
         s_rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
         wcnt += on ? 1u : 0u;
     }
+    /* Groups of un = 4 or 8 dwords, one per step, from lanes that either keep all of them or none (alac_duo.h: whole chunks
+     * inside or behind the lane's frames): the group's place in the row is worked out once, the eight stores carry
+     * immediate offsets. A lane that keeps them (`inc` = un) stands at a multiple of un (it has pushed one dword per
+     * frame); one that does not has already written its tail out (st_finish) or never had anything: it scribbles over
+     * eight dwords of its own row that nobody will look at. */
+    ALAC_DEV uint32_t st_group_base(uint32_t un) const { return lane * kRowStride + (wcnt & (kRing - un)); }
+    ALAC_DEV void st_put(uint32_t base, uint32_t j, uint32_t v, uint32_t) { s_rows[base + j] = v; }
+    ALAC_DEV void st_advance(uint32_t n) { wcnt += n; }
     /* six dwords at once (four 24-bit stereo frames): straight on from the lane's position; the one group in ten
      * that crosses the end of the ring (the same one for every lane that is still going) wraps dword by dword */
     /* (all six are stored; the lane's position moves on by `count`) */
@@ -275,8 +310,8 @@ struct GpuWave {
     }
     ALAC_DEV uint32_t ring_read(uint32_t slot) const { return s_ring[lane * kRingStride + slot]; }
     /* residual queue: row j of buffer buf holds step j of the chunk for all 64 lanes (conflict-free) */
-    ALAC_DEV void rq_write(uint32_t buf, uint32_t j, int32_t v) { s_rq[(buf * kQ + j) * kWave + lane] = v; }
-    ALAC_DEV int32_t rq_read(uint32_t buf, uint32_t j) const { return s_rq[(buf * kQ + j) * kWave + lane]; }
+    ALAC_DEV void rq_write(uint32_t buf, uint32_t j, int32_t v) { s_rq[(buf * kQRows + j) * kWave + lane] = v; }
+    ALAC_DEV int32_t rq_read(uint32_t buf, uint32_t j) const { return s_rq[(buf * kQRows + j) * kWave + lane]; }
     /* chunk hand-over between the two waves of the workgroup: LDS traffic only, so outstanding global loads
      * (ring refills, U prefetch) and stores (U tile) are NOT waited for — __syncthreads() would drain them */
     ALAC_DEV void duo_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -287,7 +322,7 @@ struct GpuWave {
     }
     /* rows of 64 cells whatever ppw is: a constant stride lets unrolled steps address their rows by immediate
      * offsets from one base, and every lane (with or without a packet) owns a column */
-    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + (size_t)i * kWave; }
+    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + ((size_t)i * kWave + lane); }
     ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * ppw; }
 };
 

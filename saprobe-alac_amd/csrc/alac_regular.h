@@ -25,6 +25,13 @@
 #ifndef ALAC_NOINLINE
 #define ALAC_NOINLINE
 #endif
+#ifndef ALAC_UNLIKELY
+#define ALAC_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif
+#ifndef ALAC_HD
+/* callable from the host side of alacgpu.hip too */
+#define ALAC_HD ALAC_DEV
+#endif
 #ifndef ALAC_SAD
 /* |a - b| + c on unsigned operands: v_sad_u32 on the GPU */
 #define ALAC_SAD(a, b, c) (((a) > (b) ? (a) - (b) : (b) - (a)) + (c))
@@ -93,6 +100,18 @@
 /* exact when both operands fit 24-bit unsigned: v_mul_u32_u24 / v_mad_u32_u24 on the GPU */
 #define ALAC_MULU24(a, b) ((uint32_t)(a) * (uint32_t)(b))
 #endif
+#ifndef ALAC_FFBH
+/* leading zeros, 0xffffffff for 0 (v_ffbh_u32 as it is: no fix-up to 32) */
+#define ALAC_FFBH(x) ((uint32_t)(x) ? (uint32_t)__builtin_clz((uint32_t)(x)) : 0xffffffffu)
+#endif
+#ifndef ALAC_SEXT_BITS
+/* the low `bits` (1..31) of x, sign-extended: one v_bfe_i32 on the GPU (the compiler makes two shifts of it) */
+#define ALAC_SEXT_BITS(x, bits) ((int32_t)((uint32_t)(x) << (32u - (bits))) >> (32u - (bits)))
+#endif
+#ifndef ALAC_BFE
+/* (x >> off[4:0]) & ((1 << width[4:0]) - 1): v_bfe_u32 on the GPU */
+#define ALAC_BFE(x, off, width) ((((uint32_t)(x)) >> ((off) & 31u)) & ((1u << ((width) & 31u)) - 1u))
+#endif
 
 namespace alac {
 
@@ -104,10 +123,18 @@ constexpr uint32_t NUM_KEYS = 2049;
 /* orders the lean decoder runs: 4/5/6/8 on exactly NA taps, the others (general form, int16 coefficient wrap) on
  * 16 register taps with wave-uniform skips; 0 copies and 31 is delta mode. 17..30 exist only on paper. */
 ALAC_DEV bool regular_order(uint32_t na) { return na <= 16 || na == 31; }
+ALAC_DEV int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
+
+/* Configurations the lean Golomb step (gol_step) covers: KB >= 1, and a PB small enough that the running mean stays
+ * below 2^25 + 512 whatever the stream holds (golomb.go:215 with n <= 0xffff and pb = PB * pbFactor / 4 <= 127: the
+ * update is a contraction towards 512 * n; the products pb * mean and mean << 2 (golomb.go:223) then never wrap and
+ * k <= 16). Every real cookie has PB 40; anything else takes the whole-packet decoder of alac_wave.h, which follows
+ * the reference's uint32 arithmetic literally. */
+ALAC_HD bool lean_config(const DevCfg& cfg) { return cfg.kb != 0 && cfg.pb <= 73u; }
 
 /* Sort key of a packet; no entropy decoding, reads only the element header. */
 ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32_t size, uint32_t avail) {
-    if (cfg.num_channels > 2 || cfg.aligned16 == 0 || cfg.kb == 0 ||
+    if (cfg.num_channels > 2 || cfg.aligned16 == 0 || !lean_config(cfg) ||
         cfg.frame_length > 65536u || cfg.frame_length <= 32u)
         return KEY_IRREGULAR;
     const Bits bits{pkt, size, avail};
@@ -161,6 +188,8 @@ ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32
  * issues the next one. So no step ever waits on an HBM/L2 round trip: the data a step needs left memory at
  * least four steps ago, and each packet byte is fetched from L2 exactly once. A plain step consumes <= 32 bits,
  * so 4 dwords per 4 steps sustain it (reseek() covers the slow path); start() prefills 16 dwords.
+ * Positions handed to the reader are BIASED: stream bit p is position p + bias, bit p + bias of the dword array that
+ * starts at `base` (the packet's start rounded down to a dword), so that no step adds the bias again.
  * Dense blob (see Bits): blocks that lie wholly inside the packet are loaded as they are (one global_load_dwordx4);
  * a block that reaches past the packet's last byte takes tail4(): aligned dwords that hold at least one packet byte
  * are fetched (they cannot leave the blob's pages), the neighbour's bytes in them are cleared, and dwords wholly
@@ -215,9 +244,9 @@ struct RingRd {
         fill += 4u;
         pend = false;
     }
-    /* channel start: synchronous prefill from the block holding `pos` */
-    ALAC_DEV void start(W& wv, uint32_t pos) {
-        const uint32_t ni = (pos + bias) >> 5;
+    /* channel start: synchronous prefill from the block holding the (biased) position */
+    ALAC_DEV void start(W& wv, uint32_t posb) {
+        const uint32_t ni = posb >> 5;
         fill = ni & ~3u;
         pend = false;
 #pragma unroll
@@ -225,10 +254,10 @@ struct RingRd {
             load4(fill);
             commit(wv);
         }
-        reseek(wv, pos);
+        reseek(wv, posb);
     }
-    ALAC_DEV void reseek(W& wv, uint32_t pos) {
-        widx = (pos + bias) >> 5;
+    ALAC_DEV void reseek(W& wv, uint32_t posb) {
+        widx = posb >> 5;
         /* a slow-path step (escape code + zero-run code) can eat more than one dword, more than tick() puts
          * back: top the ring up on the spot whenever it runs low. Plain steps take <= 32 bits (prefix + 1 + k,
          * k <= 23), which the 4 dwords per 4 steps of tick() cover. Positions are < 2^29 bits here (a live lane
@@ -241,17 +270,17 @@ struct RingRd {
         w1 = wv.ring_read((widx + 1u) & (RING - 1u));
         w2 = wv.ring_read((widx + 2u) & (RING - 1u));
     }
-    ALAC_DEV uint32_t window(uint32_t pos) const {
-        const uint32_t r = (pos + bias) & 31u;
+    ALAC_DEV uint32_t window(uint32_t posb) const {
+        const uint32_t r = posb & 31u;
         return (uint32_t)(((((uint64_t)w0) << 32) | w1) << r >> 32);
     }
     /* the cache moves by 0 or 1 dword per step (the slow path reseeks); the move is a bit mask, not a compare;
      * w2 is re-read from LDS every step */
-    ALAC_DEV void slide(W& wv, uint32_t pos) {
-        const uint32_t ni = (pos + bias) >> 5;
-        const uint32_t cm = 0u - (ni - widx);
-        w0 = (w1 & cm) | (w0 & ~cm);
-        w1 = (w2 & cm) | (w1 & ~cm);
+    ALAC_DEV void slide(W& wv, uint32_t posb) {
+        const uint32_t ni = posb >> 5;
+        const uint32_t cm = widx - ni; /* 0, or all ones when the position has entered the next dword */
+        w0 = ALAC_BFI(cm, w1, w0);
+        w1 = ALAC_BFI(cm, w2, w1);
         widx = ni;
         w2 = wv.ring_read((ni + 2u) & (RING - 1u));
     }
@@ -265,24 +294,49 @@ struct RingRd {
     }
 };
 
-/* per-lane Golomb + reader state of one channel */
+/* zrem of a lane that decodes nothing more: it has all its samples, has failed, or never had a packet. Far above any
+ * real run length (<= 65535) and any number of steps that could count it down. */
+constexpr uint32_t GOL_PARK = 0x40000000u;
+
+/* per-lane Golomb + reader state of one channel. pos and max_pos are biased (RingRd). */
 template <class W>
 struct RegLane {
     RingRd<W> rd;
     uint32_t pos, mean, zmode, zrem, pb, max_pos;
+    /* nonzero: the lane takes golomb_slow() in every step it decodes a code in. Set where the plain step's shortcuts
+     * do not hold: within reach of the packet's end (overrun, golomb.go:168) or of the channel's last sample
+     * (golomb.go:223: no zero run behind it; lock step: nothing at all behind it), and for the code that follows a
+     * zero run (zmode = 1, golomb.go:206). Recomputed at every ring top-up (gol_near) and by the slow path. */
+    uint32_t near;
     int32_t err;
+    ALAC_DEV uint32_t upos() const { return pos - rd.bias; } /* the stream position as the reference counts it */
 };
 
-/* The rare part of DynDecomp (golomb.go:167-247) for one lane: overrun, an escape code, and/or the start of a
- * zero run. Redoes the sample from its start with the stateless reader; returns the residual. Works on local
- * copies and writes the lane state back once (stores into the state from several exits make the compiler keep
- * it in scratch memory). */
+/* `near` for the steps up to the next top-up (at most 4 from step i on): a plain step takes at most 8 + 1 + 16 bits
+ * (lean_config), four of them 100; the channel's last sample is among the next four when i + 4 >= ns_live */
+template <class W>
+ALAC_DEV uint32_t gol_near(const RegLane<W>& s, uint32_t i, uint32_t ns_live) {
+    return ALAC_SUBSAT(s.pos + 128u, s.max_pos) | ALAC_SUBSAT(i + 5u, ns_live) | s.zmode;
+}
+
+/* The rare part of DynDecomp (golomb.go:167-247) for one lane: the lane's last samples and everything behind them,
+ * overrun, an escape code, the start of a zero run and the code behind one. Redoes the sample from its start with the
+ * stateless reader; returns n + zmode (what the plain step would have queued: the predictor wave folds the sign,
+ * golomb.go:206-209). Works on local copies and writes the lane state back once (stores into the state from several
+ * exits make the compiler keep it in scratch memory). ns_live: the lane's sample count, 0 once it has failed. */
 template <class W, class B>
-ALAC_DEV int32_t golomb_slow(const B& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
-                             uint32_t chan_bits, uint32_t i, uint32_t ns) {
-    uint32_t pos = s.pos, mean = s.mean, zmode = s.zmode, zrem = s.zrem;
-    int32_t err = 0, del = 0;
-    if (pos >= s.max_pos) {
+ALAC_DEV uint32_t golomb_slow(const B& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
+                              uint32_t chan_bits, uint32_t i, uint32_t ns, uint32_t& ns_live) {
+    if (i >= ns_live) { /* nothing left to decode: park the lane (it looks like one inside an endless zero run) */
+        s.zrem = GOL_PARK;
+        return 0u;
+    }
+    const uint32_t bias = s.rd.bias;
+    uint32_t pos = s.pos - bias, mean = s.mean, zmode = s.zmode, zrem = s.zrem;
+    const uint32_t max_pos = s.max_pos - bias;
+    int32_t err = 0;
+    uint32_t ndq = 0;
+    if (pos >= max_pos) {
         err = ST_OVERRUN; /* golomb.go:168-170 */
     } else {
         uint32_t m = mean >> 9;
@@ -296,9 +350,9 @@ ALAC_DEV int32_t golomb_slow(const B& bits, RegLane<W>& s, uint32_t size, uint32
             const bool five = chan_bits + gb > 32u;
             if ((gpos >> 3) > size || (five && (gpos >> 3) >= size)) err = ST_MALFORMED;
             const uint64_t w2 = bits.window(gpos);
-        if (chan_bits == 0) n = 0;
-        else if (chan_bits <= 32) n = (uint32_t)(w2 >> (64u - chan_bits));
-        else n = (uint32_t)(w2 >> 31) & ((2u << gb) - 1u); /* numBits 33: only byte 5 survives (golomb.go:90-99) */
+            if (chan_bits == 0) n = 0;
+            else if (chan_bits <= 32) n = (uint32_t)(w2 >> (64u - chan_bits));
+            else n = (uint32_t)(w2 >> 31) & ((2u << gb) - 1u); /* numBits 33: only byte 5 survives (golomb.go:90-99) */
             pos += 9u + chan_bits;
         } else {
             const uint32_t v = (w << (n + 1u)) >> (32u - k);
@@ -307,8 +361,9 @@ ALAC_DEV int32_t golomb_slow(const B& bits, RegLane<W>& s, uint32_t size, uint32
         }
         if (err == 0) {
             const uint32_t nd = n + zmode;
-            const int32_t half = (int32_t)((nd + 1u) >> 1);
-            del = (nd & 1u) ? -half : half;
+            /* golomb.go:206-209 computes (nd + 1) >> 1 in uint32: for nd = 2^32 - 1 that is 0, not 2^31. The predictor
+             * wave unfolds (nd >> 1) ^ -(nd & 1), which agrees everywhere else: hand it a 0 in that one case. */
+            ndq = nd == 0xffffffffu ? 0u : nd;
             mean = s.pb * nd + mean - ((s.pb * mean) >> 9);
             if (n > 0xffffu) mean = 0xffffu;
             zmode = 0;
@@ -340,66 +395,133 @@ ALAC_DEV int32_t golomb_slow(const B& bits, RegLane<W>& s, uint32_t size, uint32
             }
         }
     }
-    const bool ok = err == 0;
-    s.pos = ok ? pos : s.pos;
-    s.mean = ok ? mean : s.mean;
-    s.zmode = ok ? zmode : s.zmode;
-    s.zrem = ok ? zrem : s.zrem;
+    if (err == 0) {
+        s.pos = pos + bias;
+        s.mean = mean;
+        s.zmode = zmode;
+        s.zrem = zrem;
+        /* the steps up to the next top-up: at most three (gol_near) */
+        s.near = ALAC_SUBSAT(pos + bias + 128u, s.max_pos) | ALAC_SUBSAT(i + 5u, ns_live) | zmode;
+        return ndq;
+    }
     s.err = err;
-    return del;
+    s.zrem = GOL_PARK;
+    ns_live = 0u;
+    return 0u;
 }
 
 /*
- * One residual (DynDecomp, golomb.go:167-247), the form the entropy wave of alac_duo.h runs: a lone wave pays for
- * EVERY instruction it issues (scalar ones and branches included, ~4-5 cycles each) and a v_cmp / v_cndmask pair
- * costs ~17, so the step is written as plain integer arithmetic on bit masks: no compare, no select and no
- * exec-mask juggling on the common path; the one branch left is the rare part (golomb_slow).
- * ns_live: the lane's sample count, 0 once the lane has failed (i >= ns_live: a dead step, nothing moves).
- * on_mask: ~0 when i < ns_live, carried from the previous step (updated here for step i+1).
+ * One residual (DynDecomp, golomb.go:167-247), the form the entropy wave of alac_duo.h and the scan run. Every
+ * instruction of the step costs the same (a lone wave issues a dependent one every 8.3 cycles, two waves on a SIMD
+ * one every 4.2 between them: profiles/microbench), so the step is written for the fewest of them: plain integer
+ * arithmetic on bit masks, no select, no sign folding (the predictor wave does that), one branch for everything rare
+ * (golomb_slow). What lets it be short:
+ *  - k is kept as 31 - k (v_ffbh gives it that way round) and the code's value is one bit-field extract;
+ *  - a lane inside a zero run (zrem != 0; a parked lane is one too) queues a 0 and moves nothing: its n is masked, and
+ *    with n = 0 and mean = 0 (where a run leaves it, golomb.go:245) the mean update yields 0 again by itself;
+ *  - overrun, the end of the lane's samples and zmode are not tested here at all: `near` sends the lane to the slow
+ *    path while any of them is within reach (RegLane).
+ * Returns n + zmode (0 inside a run).
  */
-template <class W, class B>
-ALAC_DEV int32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
-                          uint32_t chan_bits, uint32_t i, uint32_t ns, uint32_t& ns_live, uint32_t& on_mask) {
-    const uint32_t k = umin(31u - clz32((s.mean >> 9) + 3u), kb); /* 1..23 */
-    const uint32_t w = s.rd.window(s.pos);
-    const uint32_t pre = clz32(~w);
-    const uint32_t v = (w << ((pre + 1u) & 31u)) >> (32u - k);
-    const uint32_t vm1 = ALAC_SUBSAT(v, 1u);           /* v >= 2: value v - 1 and k bits; else 0 and k - 1 bits */
-    const uint32_t n = (pre << k) - pre + vm1;          /* pre * (2^k - 1) + ... */
-    const uint32_t nd = n + s.zmode;
-    const uint32_t mean2 = s.pb * nd + s.mean - ((s.pb * s.mean) >> 9); /* golomb.go:215 */
-    /* masks: lane decodes a code in this step (alive, not inside a zero run) */
-    const uint32_t next_on = (uint32_t)((int32_t)(i + 1u - ns_live) >> 31); /* i + 1 < ns_live (both < 2^31) */
-    const uint32_t norun = (uint32_t)((int32_t)(s.zrem - 1u) >> 31);        /* zrem == 0 (zrem <= 65535) */
-    const uint32_t okm = on_mask & norun;
-    /* rare cases, as nonzero-means-true flags: overrun (golomb.go:168), escape code (:184), n > 0xffff (:216),
-     * start of a zero run (:223: mean * 4 < 512 with a sample left; mean2 < 2^25 here, the shift cannot wrap) */
-    const uint32_t rare = (ALAC_SUBSAT(s.pos + 1u, s.max_pos) | ((pre + 7u) >> 4) | (n >> 16) |
-                           (ALAC_SUBSAT(128u, mean2) & next_on)) & okm;
-    const uint32_t hm = (nd + 1u) >> 1; /* golomb.go:206-209 */
-    const uint32_t sg = 0u - (nd & 1u);
-    int32_t del = (int32_t)(((hm ^ sg) - sg) & norun);
-    const uint32_t o_pos = s.pos, o_mean = s.mean, o_zmode = s.zmode, o_zrem = s.zrem;
-    s.pos = o_pos + ((pre + k + umin(vm1, 1u)) & okm); /* prefix + 1, then k bits (v >= 2) or k - 1 */
-    s.mean = ALAC_BFI(okm, mean2, o_mean);
-    s.zmode = o_zmode & ~okm;
-    s.zrem = ALAC_SUBSAT(o_zrem, 1u);
-    on_mask = next_on;
-    /* a plain divergent branch: one compare, one exec-mask save and a skip when no lane is in there (wrapping it
-     * in a wave-wide any() first only adds scalar instructions to every step) */
-    if (rare != 0u) {
-        s.pos = o_pos;
-        s.mean = o_mean;
-        s.zmode = o_zmode;
-        s.zrem = o_zrem;
-        del = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns);
-        s.rd.reseek(wv, s.pos);
-        ns_live = s.err ? 0u : ns_live;
-        on_mask = (uint32_t)((int32_t)(i + 1u - ns_live) >> 31);
+template <bool ESC, class W, class B>
+ALAC_DEV uint32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb, uint32_t c31kb,
+                           uint32_t chan_bits, uint32_t i, uint32_t ns, uint32_t& ns_live) {
+    /* ISSUE ORDER. The build keeps source order (csrc/Makefile), a wave issues in order, and an instruction whose
+     * operand comes from the instruction right before it waits 8.3 cycles instead of 4.8 (profiles/microbench/valu_more,
+     * chains=1): a lone wave running this step as one dependent chain needs twice the time of one that always has an
+     * independent instruction at hand. The step is three chains — P: position -> window -> prefix -> value -> position;
+     * M: mean -> k, and mean * pb; Z: the zero-run countdown — and the statements below alternate between them so that
+     * (almost) nothing uses the result of its predecessor. The slide of the window cache is done here too, before the
+     * rare cases are known: the slow path reseeks anyway. ESC: escape codes take a few instructions of their own
+     * behind a wave-uniform branch (entropy wave of a pair: it has issue slots to spare); without it they are one more
+     * rare case (the scan: a lone chain, where two instructions more in every step cost more than the rare detour). */
+    const uint32_t o_pos = s.pos, o_mean = s.mean, o_zrem = s.zrem;
+    RingRd<W>& rd = s.rd;
+#ifdef ALAC_PAD_A /* experiment: what an instruction more in the entropy step costs */
+    {
+        uint32_t pad_ = i;
+#pragma unroll
+        for (int t_ = 0; t_ < ALAC_PAD_A; ++t_) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad_));
     }
-    s.rd.slide(wv, s.pos);
-    return del;
+#endif
+    const uint32_t r = o_pos & 31u;                                                     /* P */
+    const uint32_t x9 = o_mean >> 9;                                                    /* M */
+    const uint32_t w = (uint32_t)(((((uint64_t)rd.w0) << 32) | rd.w1) << r >> 32);      /* P: the 32 stream bits at pos */
+    const uint32_t x3 = x9 + 3u;                                                        /* M */
+    const uint32_t nw = ~w;                                                             /* P */
+    const uint32_t c = ALAC_FFBH(x3);                                                   /* M: 31 - lg3a(mean >> 9) */
+    const uint32_t pre = ALAC_FFBH(nw); /* P: leading ones; all 32 read as 2^32 - 1: rare either way */
+    /* k = min(lg3a(mean >> 9), KB), golomb.go:172-174, as ck = 31 - k; c31kb = 31 - KB as a signed number */
+    const uint32_t ck = (uint32_t)imax((int32_t)c, (int32_t)c31kb);                     /* M */
+    const uint32_t z1 = o_zrem - 1u;                                                    /* Z */
+    const uint32_t k = 31u - ck; /* 1..16 */                                            /* M */
+    const uint32_t off = ck - pre;                                                      /* P */
+    const uint32_t norun = (uint32_t)((int32_t)z1 >> 31); /* zrem == 0 (zrem < 2^31) */ /* Z */
+    const uint32_t v = ALAC_BFE(w, off, k); /* the k bits behind the prefix and its 0 (golomb.go:192) */
+    const uint32_t pm = s.pb * o_mean;                                                  /* M */
+    const uint32_t zrem2 = ALAC_SUBSAT(o_zrem, 1u);                                     /* Z */
+    const uint32_t vm1 = ALAC_SUBSAT(v, 1u); /* v >= 2: value v - 1 and k bits; else 0 and k - 1 bits */
+    const uint32_t t9 = pm >> 9;                                                        /* M */
+    const uint32_t pk = pre << k;                                                       /* P */
+    const uint32_t c2 = umin(vm1, 1u);
+    const uint32_t mt = o_mean - t9;                                                    /* M */
+    uint32_t n = pk + vm1 - pre;             /* pre * (2^k - 1) + ... */
+    uint32_t cons = pre + k + c2;            /* prefix + 1, then k bits (v >= 2) or k - 1 */
+    uint32_t esc_flag = 0;
+    if (ESC) {
+        /* Nine ones: an escape code, the value is the chan_bits bits behind them (golomb.go:184-186). One sample in two
+         * thousand of music has one, which is one step in thirty of a wave of 64: for chan_bits <= 23 the whole code
+         * lies in the window already (a lane within reach of the packet's end takes the slow path anyway: near). Wider
+         * values are left to golomb_slow: an n that trips the n > 0xffff flag sends the lane there. */
+        const uint32_t esc = ALAC_SUBSAT(pre, 8u) & norun;
+        if (ALAC_UNLIKELY(wv.any(esc != 0u))) {
+            if (esc != 0u) {
+                const bool inl = chan_bits <= 23u;
+                n = inl ? ALAC_BFE(w, 23u - chan_bits, chan_bits) : 0xffffffffu;
+                cons = 9u + chan_bits;
+            }
+        }
+    } else {
+        esc_flag = ALAC_SUBSAT(pre, 8u);
+    }
+    n &= norun;
+    const uint32_t cm = cons & norun;
+    const uint32_t mean2 = ALAC_MULU24(s.pb, n) + mt; /* golomb.go:215; n <= 0xffff or rare */
+    const uint32_t pos2 = o_pos + cm;
+    const uint32_t nhi = (n >> 16) | esc_flag;
+    const uint32_t ni = pos2 >> 5;
+    const uint32_t zs = ALAC_SUBSAT(128u, mean2);
+    const uint32_t cmk = rd.widx - ni; /* 0, or all ones when the position has entered the next dword */
+    /* rare cases, as nonzero-means-true flags: (escape code, golomb.go:184,) n > 0xffff (:216), near (RegLane), start of
+     * a zero run (:223: mean * 4 < 512; mean2 < 2^26, the shift cannot wrap) */
+    const uint32_t fl = nhi | s.near | zs;
+    const uint32_t nw0 = ALAC_BFI(cmk, rd.w1, rd.w0);
+    const uint32_t rare = fl & norun;
+    const uint32_t nw1 = ALAC_BFI(cmk, rd.w2, rd.w1);
+    s.pos = pos2;
+    s.mean = mean2;
+    s.zrem = zrem2;
+    rd.w0 = nw0;
+    rd.w1 = nw1;
+    rd.widx = ni;
+    rd.w2 = wv.ring_read((ni + 2u) & (RingRd<W>::RING - 1u));
+    uint32_t ndq = n;
+    /* a wave-uniform branch around the divergent one: the plain path then holds one compare and one scalar branch, and
+     * whatever the compiler needs to merge the two lanes' worth of state (copies, saved exec masks) stays in there */
+    if (ALAC_UNLIKELY(wv.any(rare != 0u))) {
+        if (rare != 0u) {
+            s.pos = o_pos;
+            s.mean = o_mean;
+            s.zrem = o_zrem;
+            ndq = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns, ns_live);
+            rd.reseek(wv, s.pos); /* the window cache afresh */
+        }
+    }
+    return ndq;
 }
+
+/* what the entropy wave queues -> the residual (golomb.go:206-209: del = ((nd + 1) >> 1) * (-(nd & 1) | 1)) */
+ALAC_DEV int32_t gol_unfold(uint32_t nd) { return (int32_t)((nd >> 1) ^ (0u - (nd & 1u))); }
 
 /* ---- predictor step for i > na (UnpcBlock, predictor.go:99-684), chanBits <= 23 ---------------------------------
  * hb[j] = out[i-1-j] ^ BIAS (sign-biased history: |a - b| of biased values is one unsigned sad). Taps walked from
@@ -408,8 +530,9 @@ ALAC_DEV int32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, ui
  * t_j < 2^27: nothing wraps, which is what makes this equal to the reference's signed countdown.
  * GEN: the wave-uniform order na on NR = 16 register taps; WRAP: int16 coefficients (predictor.go:664,675). */
 template <int NR, bool GEN, bool WRAP, bool CB_POS = false>
-ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1], uint32_t na, int32_t del,
-                                uint32_t den_shift, int32_t den_half, uint32_t rnd_neg, uint32_t chan_shift) {
+ALAC_DEV int32_t predict_narrow_core(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1], uint32_t na, int32_t del, uint32_t sgnm,
+                                     uint32_t nsg, int32_t rem, uint32_t den_shift, int32_t den_half, uint32_t rnd_neg,
+                                     uint32_t chan_shift) {
     constexpr uint32_t BIAS = 0x80000000u;
     uint32_t topb = hb[NR];
     if (GEN) {
@@ -417,14 +540,19 @@ ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1
         for (int j = 1; j < NR; ++j)
             if (na == (uint32_t)j) ALAC_PICK(topb, hb[j]); /* scalar branch: na is wave-uniform */
     }
+#ifdef ALAC_PAD_B /* experiment: what an instruction more in the predictor step costs */
+    {
+        uint32_t pad_ = na;
+#pragma unroll
+        for (int t_ = 0; t_ < ALAC_PAD_B; ++t_) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad_));
+    }
+#endif
     /* no compares on the hot path (a v_cmp / v_cndmask pair costs a lone wave ~17 cycles, plain ALU ops ~5):
-     * everything that depends on the sign of the residual is derived from its sign mask */
-    const uint32_t sgnm = (uint32_t)(del >> 31); /* ~0 for del < 0 */
-    const uint32_t nsg = (uint32_t)del >> 31;    /* 1 for del < 0 */
+     * everything that depends on the sign of the residual is derived from its sign mask
+     * (sgnm: ~0 for del < 0, nsg: 1 for del < 0) */
     const uint32_t rnd = rnd_neg & sgnm;
-    /* D0 = |del|: what is left of it after the taps above. Signed and never wrapping: the taps take at most
+    /* rem = D0 = |del|: what is left of it after the taps above. Signed and never wrapping: the taps take at most
      * sum(na - j) * 2^23 = 136 * 2^23 < 2^31 away from a value >= 0 */
-    int32_t rem = (int32_t)(((uint32_t)del ^ sgnm) + nsg);
     /* den_half - sum coef_j * (top - h_j), as one multiply-add chain over e_j = h_j - top.
      * The build runs with the pre-RA scheduler off (csrc/Makefile), so the instructions issue in THIS order: each
      * tap's nine instructions together. Measured against the alternative of one operation at a time over all taps
@@ -434,6 +562,10 @@ ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1
 #pragma unroll
     for (int j = NR - 1; j >= 0; --j) {
         if (GEN && (uint32_t)j >= na) continue; /* scalar branch: taps the order does not have */
+#ifndef ALAC_TAP_ORDER
+#define ALAC_TAP_ORDER 1
+#endif
+#if ALAC_TAP_ORDER == 0
         const int32_t e = (int32_t)(hb[j] - topb); /* out[i-1-j] - top; the bias cancels */
         acc = ALAC_MAD24(coef[j], e, acc);         /* uses coef[j] before its update */
         /* coefficient step sign(del) * -sign(top - h_j) = sign(del) * sign(e): (sign(e) ^ sgnm) + nsg */
@@ -443,10 +575,45 @@ ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1
         const int32_t cj = ALAC_MAD24(delta, go, coef[j]);
         coef[j] = WRAP ? (int32_t)(int16_t)cj : cj; /* predictor.go:664,675 */
         rem = ALAC_MSUB24(rem, q, na - (uint32_t)j);
+#else
+        /* Issue order (the build keeps source order, csrc/Makefile): a wave issues in order, an instruction that needs
+         * the result of the one right before it waits 8.3 cycles instead of 4.8 (profiles/microbench/valu_more: chains=1),
+         * and the predictor wave's own issue rate is what a pair's step takes (round 3: ten instructions more in it cost
+         * 8 %, twenty more in the entropy wave 1 %). So no instruction here uses the result of its predecessor. */
+        const int32_t e = (int32_t)(hb[j] - topb);            /* out[i-1-j] - top; the bias cancels */
+        const uint32_t ae = ALAC_SAD(topb, hb[j], rnd);       /* |e| + rounding */
+        const int32_t sg = ALAC_SIGN(e);
+        acc = ALAC_MAD24(coef[j], e, acc);                    /* uses coef[j] before its update */
+        const uint32_t q = ae >> den_shift;
+        const int32_t go = ALAC_CLAMP01(rem);                 /* tap j adapts while the budget is not used up */
+        /* coefficient step sign(del) * -sign(top - h_j) = sign(del) * sign(e): (sign(e) ^ sgnm) + nsg */
+        const int32_t delta = (int32_t)ALAC_XAD(sg, sgnm, nsg);
+        rem = ALAC_MSUB24(rem, q, na - (uint32_t)j);
+        const int32_t cj = ALAC_MAD24(delta, go, coef[j]);
+        coef[j] = WRAP ? (int32_t)(int16_t)cj : cj;           /* predictor.go:664,675 */
+#endif
     }
     const int32_t o = del + (int32_t)(topb ^ BIAS) + (acc >> den_shift);
     /* CB_POS: the caller knows chanBits >= 1, so the shift count is <= 31 and sext_cs' guard for 32 is not needed */
-    return CB_POS ? (int32_t)((uint32_t)o << chan_shift) >> chan_shift : sext_cs(o, chan_shift);
+    return CB_POS ? ALAC_SEXT_BITS(o, 32u - chan_shift) : sext_cs(o, chan_shift);
+}
+
+/* the step from the residual itself ... */
+template <int NR, bool GEN, bool WRAP, bool CB_POS = false>
+ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1], uint32_t na, int32_t del,
+                                uint32_t den_shift, int32_t den_half, uint32_t rnd_neg, uint32_t chan_shift) {
+    const uint32_t sgnm = (uint32_t)(del >> 31), nsg = (uint32_t)del >> 31;
+    return predict_narrow_core<NR, GEN, WRAP, CB_POS>(coef, hb, na, del, sgnm, nsg, (int32_t)(((uint32_t)del ^ sgnm) + nsg), den_shift,
+                                                      den_half, rnd_neg, chan_shift);
+}
+/* ... and from what the entropy wave queues, nd = n + zmode (gol_step): sign, magnitude and residual all come out of
+ * its lowest bit and the rest (golomb.go:206-209), cheaper here than folding there and taking the sign apart again */
+template <int NR, bool GEN, bool WRAP, bool CB_POS = false>
+ALAC_DEV int32_t predict_narrow_nd(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1], uint32_t na, uint32_t nd,
+                                   uint32_t den_shift, int32_t den_half, uint32_t rnd_neg, uint32_t chan_shift) {
+    const uint32_t nsg = nd & 1u, sgnm = 0u - nsg, hm = nd >> 1;
+    return predict_narrow_core<NR, GEN, WRAP, CB_POS>(coef, hb, na, (int32_t)(hm ^ sgnm), sgnm, nsg, (int32_t)(hm + nsg), den_shift,
+                                                      den_half, rnd_neg, chan_shift);
 }
 
 /* The same step for chanBits > 23 (32-bit streams without shift bytes): the literal form of predictor.go:99-684 on
@@ -494,9 +661,10 @@ enum { OUT_UTILE = 0,  /* U of a pair: hand-off tile */
        OUT_RAW = 3 };  /* int32 samples into this lane's row (split pipeline, alac_split.h) */
 
 /* Entropy scan of one channel for decode_wave<..., SCAN>: the lean Golomb loop. With res_row (wave-uniform: all
- * lanes or none) the residuals are kept: four per 16-byte store into the lane's row, so that the split pipeline's
- * predictor pass (alac_split.h) does not have to decode the stream a second time. Rows hold frame_length + 3 samples
- * rounded up to 4, lanes write whole groups of four up to the wave's longest channel (ns <= frame_length). */
+ * lanes or none) what the steps yield (n + zmode, the sign not folded yet: gol_unfold) is kept: four per 16-byte store
+ * into the lane's row, so that the split pipeline's predictor pass (alac_split.h) does not have to decode the stream a
+ * second time. Rows hold frame_length + 3 values rounded up to 4, lanes write whole groups of four up to the wave's
+ * longest channel (ns <= frame_length). */
 template <class W, class B>
 ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_t* pkt, uint32_t size, bool go,
                            uint32_t& pos, uint32_t ns, uint32_t pb_local, uint32_t chan_bits, int32_t& err,
@@ -504,42 +672,47 @@ ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_
     RegLane<W> s;
     s.rd.init(pkt, size);
     s.err = 0;
-    s.max_pos = size * 8u;
-    s.pos = go ? pos : 0u;
+    s.max_pos = size * 8u + s.rd.bias;
+    s.pos = (go ? pos : 0u) + s.rd.bias;
     s.mean = cfg.mb;
     s.zmode = 0;
     s.zrem = 0;
+    s.near = 0;
     s.pb = pb_local;
     const uint32_t my_ns = go ? ns : 0u;
     const uint32_t n_it = wv.max_u32(my_ns);
     uint32_t kb = cfg.kb;
     ALAC_OWN_REG(kb);
     const uint32_t wb = go_shl(1u, kb) - 1u; /* golomb.go:60 */
+    const uint32_t c31kb = 31u - kb;
     s.rd.start(wv, s.pos);
     uint32_t ns_live = my_ns;
-    uint32_t on_mask = (uint32_t)((int32_t)(0u - ns_live) >> 31);
     const bool keep = res_row != nullptr;
     /* the four residuals of a group are stored at the top of the NEXT group, right behind the ring's top-up: vector
      * memory operations retire in order (vmcnt), so a store issued just before a top-up's wait would make the entropy
      * chain wait for the store's round trip; issued right after it, it has four steps to drain */
-    int32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+    uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
     uint32_t i = 0;
     for (; i + 4u <= n_it; i += 4u) { /* four steps per ring top-up, straight-line */
         s.rd.tick(wv);
-        if (keep && go && i != 0u) ALAC_STORE4(res_row + (i - 4u), h0, h1, h2, h3);
-        h0 = gol_step(wv, bits, s, size, kb, wb, chan_bits, i, my_ns, ns_live, on_mask);
-        h1 = gol_step(wv, bits, s, size, kb, wb, chan_bits, i + 1u, my_ns, ns_live, on_mask);
-        h2 = gol_step(wv, bits, s, size, kb, wb, chan_bits, i + 2u, my_ns, ns_live, on_mask);
-        h3 = gol_step(wv, bits, s, size, kb, wb, chan_bits, i + 3u, my_ns, ns_live, on_mask);
+        s.near = gol_near(s, i, ns_live);
+        if (keep && go && i != 0u) ALAC_STORE4(res_row + (i - 4u), (int32_t)h0, (int32_t)h1, (int32_t)h2, (int32_t)h3);
+        h0 = gol_step<false>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i, my_ns, ns_live);
+        h1 = gol_step<false>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i + 1u, my_ns, ns_live);
+        h2 = gol_step<false>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i + 2u, my_ns, ns_live);
+        h3 = gol_step<false>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i + 3u, my_ns, ns_live);
     }
-    if (keep && go && i != 0u) ALAC_STORE4(res_row + (i - 4u), h0, h1, h2, h3);
+    if (keep && go && i != 0u) ALAC_STORE4(res_row + (i - 4u), (int32_t)h0, (int32_t)h1, (int32_t)h2, (int32_t)h3);
     for (; i < n_it; ++i) {
-        if ((i & 3u) == 0) s.rd.tick(wv);
-        const int32_t d = gol_step(wv, bits, s, size, kb, wb, chan_bits, i, my_ns, ns_live, on_mask);
-        if (keep && go) res_row[i] = d;
+        if ((i & 3u) == 0) {
+            s.rd.tick(wv);
+            s.near = gol_near(s, i, ns_live);
+        }
+        const uint32_t d = gol_step<false>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i, my_ns, ns_live);
+        if (keep && go) res_row[i] = (int32_t)d;
     }
     if (go) {
-        pos = s.pos;
+        pos = s.upos();
         err = s.err;
     }
 }

@@ -48,7 +48,8 @@ ALAC_DEV void decode_channel_task(W& wv, const DevCfg& cfg, uint32_t key, bool l
     RegLane<W> s;
     s.rd.init(pkt, size);
     s.err = 0;
-    s.max_pos = size * 8u;
+    s.near = 0;
+    s.max_pos = size * 8u + s.rd.bias;
     const uint32_t h = bits.get(d.hdr_pos, 16);
     const uint32_t mode = live ? (h >> 12) : 0u;
     const uint32_t den_shift = (h >> 8) & 0xfu;
@@ -56,7 +57,7 @@ ALAC_DEV void decode_channel_task(W& wv, const DevCfg& cfg, uint32_t key, bool l
     s.mean = cfg.mb;
     s.zmode = 0;
     s.zrem = 0;
-    s.pos = live ? d.ent_pos : 0u;
+    s.pos = (live ? d.ent_pos : 0u) + s.rd.bias;
     const uint32_t ns = live ? d.ns : 0u;
     const uint32_t chan_bits = live ? ((d.info >> CD_CHANBITS_SHIFT) & 63u) : 16u;
     const uint32_t n_it = wv.max_u32(ns);

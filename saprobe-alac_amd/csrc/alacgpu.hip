@@ -29,6 +29,9 @@ using namespace alack;
 namespace {
 
 thread_local char g_err[512] = "";
+#ifdef ALAC_DUO_PROF
+Plan* g_prof_plan = nullptr; /* profiling build: the plan of the last decode (alacgpu_debug_prof) */
+#endif
 
 void set_err(const char* fmt, ...) {
     va_list ap;
@@ -329,6 +332,9 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
     alac::DevCfg c = dec->dev_cfg;
     c.aligned16 = (out_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(d_out) % 16) == 0) ? 1u : 0u;
     Plan* plan = (Plan*)dec->plan.p;
+#ifdef ALAC_DUO_PROF
+    g_prof_plan = plan;
+#endif
     const uint32_t* sz = (const uint32_t*)dec->sizes_ws.p; /* the checked sizes (alac_classify) */
     const uint32_t nb = (uint32_t)((n + 255) / 256);
     const uint32_t slot = (uint32_t)(dec->launches % kTimingSlots);
@@ -345,7 +351,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
                        d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw, (alac::ChanDesc*)dec->cd.p,
                        (alac::PktDesc*)dec->pd.p, dec->cfg.num_channels > 2 ? (int32_t*)dec->rows.p : (int32_t*)nullptr,
                        (uint64_t)row_stride_of(dec->cfg.frame_length));
-    if (dec->cfg.num_channels <= 2 && dec->cfg.kb != 0) {
+    if (dec->cfg.num_channels <= 2 && alac::lean_config(c)) {
         /* one kernel per class of regular packets (alac_gpu.h, k_decode_body.inc): each one is launched over all the wave
          * slots and leaves the slots of the other classes alone. gated_cap: how many pairs per CU the gated twin of the
          * kernel can hold (0: it has none); which of the twins works is decided on the device. */
@@ -373,7 +379,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
         }
     }
     HIP_TRY(hipGetLastError());
-    if (dec->cfg.kb != 0) {
+    if (alac::lean_config(c)) {
         /* irregular packets were only scanned by alac_scan (status, frames, channel descriptors) */
         const uint64_t rs = row_stride_of(dec->cfg.frame_length);
         /* frames per interleave block: one wavefront's worth keeps more blocks in flight per CU (the kernel waits on
@@ -787,11 +793,11 @@ int alacgpu_synchronize(alacgpu_decoder* d) {
 const char* alacgpu_last_error(void) { return g_err; }
 
 #ifdef ALAC_DUO_PROF
-/* profiling build only: read and clear the stamp sums ([0..3] role A, [8..11] role B) */
+/* profiling build only: the stamp sums of the last decode ([0..3] role A, [8..11] role B) */
 int alacgpu_debug_prof(unsigned long long* out16) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_duo_prof), sizeof(g_duo_prof)) != hipSuccess) return ALACGPU_E_HIP;
-    unsigned long long z[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_duo_prof), z, sizeof(z)) != hipSuccess) return ALACGPU_E_HIP;
+    if (!g_prof_plan) return ALACGPU_E_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return ALACGPU_E_HIP;
+    if (hipMemcpy(out16, g_prof_plan->prof, sizeof(g_prof_plan->prof), hipMemcpyDeviceToHost) != hipSuccess) return ALACGPU_E_HIP;
     return ALACGPU_E_OK;
 }
 #endif

@@ -27,7 +27,7 @@ alac_scan(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_byte
     const uint32_t pkt = live ? perm[plan->pkt_start[key] + idx] : 0u;
 
     GpuWave wv;
-    wv.u_tile = scratch_u + (size_t)b * u_tile_cells(cfg.frame_length) + lane;
+    wv.u_tile = scratch_u + (size_t)b * u_tile_cells(cfg.frame_length);
     wv.g_tile = scratch_g + (size_t)b * kFallbackSlots * ppw + lane;
     wv.ppw = ppw;
     wv.my_out = nullptr;
@@ -77,7 +77,7 @@ alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_by
     if (__ballot(live) == 0ull) return;
 
     GpuWave wv;
-    wv.u_tile = scratch_u + (size_t)b * u_tile_cells(cfg.frame_length) + lane;
+    wv.u_tile = scratch_u + (size_t)b * u_tile_cells(cfg.frame_length);
     wv.g_tile = scratch_g + (size_t)b * kFallbackSlots * ppw + lane;
     wv.ppw = ppw;
     wv.my_out = nullptr;

@@ -40,9 +40,9 @@ alac_classify(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_
             sizes_ws[i] = (uint32_t)sz;
             const uint8_t* p = blob + off;
             uint32_t key = alac::classify_regular(cfg, p, (uint32_t)sz, avail_of(blob_bytes, off));
-            /* not regular: scan first (with a usable KB). More than two channels: split pipeline. One or two: escape
+            /* not regular: scan first (configurations the lean Golomb step covers, alac_regular.h: lean_config). More than two channels: split pipeline. One or two: escape
              * elements are unpacked by alac_interleave, anything else is handed to the whole-packet decoder. */
-            if (key == alac::KEY_IRREGULAR) key = cfg.kb != 0 ? kKeyScan : kKeyLegacy;
+            if (key == alac::KEY_IRREGULAR) key = alac::lean_config(cfg) ? kKeyScan : kKeyLegacy;
             keys[i] = (uint16_t)key;
             atomicAdd(&hist[key], 1u);
         }

@@ -45,6 +45,11 @@ struct HostWave {
     void st_push_if(uint32_t v, bool on) {
         if (on) st_push(v);
     }
+    uint32_t st_group_base(uint32_t) const { return st_cnt; }
+    void st_put(uint32_t base, uint32_t j, uint32_t v, uint32_t inc) {
+        if (inc) memcpy(st_out + 4u * (size_t)(base + j), &v, 4);
+    }
+    void st_advance(uint32_t n) { st_cnt += n; }
     void st_push6_n(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t d4, uint32_t d5, uint32_t count) {
         const uint32_t d[6] = {d0, d1, d2, d3, d4, d5};
         for (uint32_t k = 0; k < count; ++k) st_push(d[k]);
@@ -63,7 +68,7 @@ struct HostWave {
     }
     uint32_t ring_read(uint32_t slot) const { return ring[slot]; }
     /* residual queue of alac_duo.h: one lane, both roles played by the same caller, so the barriers are no-ops */
-    int32_t rq[2][alac::DUO_CHUNK] = {{0}};
+    int32_t rq[2][alac::DUO_CHUNK + alac::DUO_CHUNK / 2] = {{0}};
     void rq_write(uint32_t buf, uint32_t j, int32_t v) { rq[buf][j] = v; }
     int32_t rq_read(uint32_t buf, uint32_t j) const { return rq[buf][j]; }
     void duo_sync() {}
@@ -153,7 +158,7 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
                 continue;
             }
         }
-        if (variant < 0 && dc.kb != 0) {
+        if (variant < 0 && alac::lean_config(dc)) {
             /* split pipeline, as alacgpu.hip runs it: scan -> one lean phase per channel -> interleave */
             alac::ChanDesc cd[8];
             memset(cd, 0, sizeof(cd));

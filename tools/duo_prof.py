@@ -22,20 +22,19 @@ d_st = torch.full((P,), -1, dtype=torch.int32, device=dev)
 dec = pkg.NewPacketDecoder(cfg, 0)
 dec.reserve(P)
 L = ctypes.CDLL(pkg.lib_path())
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 32)()
 def step():
     dec.decode_batch_device(d_blob.data_ptr(), d_blob.numel(), d_off.data_ptr(), d_sz.data_ptr(), P, d_out.data_ptr(), stride,
                             d_fr.data_ptr(), d_st.data_ptr(), sync=True)
-step(); step()
-L.alacgpu_debug_prof(buf)
-step()
+step(); step(); step()
 L.alacgpu_debug_prof(buf)
 v = list(buf)
 names = ["A:fetch+golomb", "B:predict", "A:emit", "barrier wait"]
 waves = (P + 63) // 64
-for role, off in (("A", 0), ("B", 8)):
-    tot = sum(v[off:off + 4])
-    print("role %s (ticks of s_memtime per wave, %d waves):" % (role, waves))
-    for k in range(4):
-        print("   %-16s %12.0f  %5.1f %%" % (names[k], v[off + k] / waves, 100.0 * v[off + k] / max(tot, 1)))
+for role, off in (("A", 0), ("B", 16)):
+    for phase, po in (("U phase", 0), ("last phase", 4)):
+        tot = sum(v[off + po:off + po + 4])
+        print("role %s, %s (ticks of s_memtime per wave, %d waves; %.1f per step of 4096):" % (role, phase, waves, tot / waves / 4096))
+        for k in range(4):
+            print("   %-16s %12.0f  %5.1f %%" % (names[k], v[off + po + k] / waves, 100.0 * v[off + po + k] / max(tot, 1)))
 print("kernel ms:", dec.kernel_times_ms()[-1:])
