@@ -205,8 +205,8 @@ def main():
             for _ in range(3):  # first call allocates the staging buffers
                 h_st[:] = -1
                 t0 = time.perf_counter()
-                pkg._check(dec._lib.alacgpu_decode_batch(dec._h, dense.ctypes.data, pk_off.ctypes.data, P, h_out.ctypes.data,
-                                                         frame_bytes, h_fr.ctypes.data, h_st.ctypes.data))
+                pkg._check(dec._lib.alacgpu_decode_batch(dec._h, dense.ctypes.data, dense.size, pk_off.ctypes.data, P,
+                                                         h_out.ctypes.data, frame_bytes, h_fr.ctypes.data, h_st.ctypes.data))
                 dt = time.perf_counter() - t0
                 best = dt if best is None else min(best, dt)
             ok = bool((h_st == 0).all()) and bool(np.array_equal(h_fr, b.frames))

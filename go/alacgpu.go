@@ -11,9 +11,9 @@
 //	CGO_LDFLAGS="-L$REPO/saprobe-alac_amd/csrc -lalacgpu -Wl,-rpath,$REPO/saprobe-alac_amd/csrc" \
 //	go test -tags alacgpu ./...
 //
-// The image this repository is built in has no Go toolchain: the file is kept in step with the header by
-// tests/test_abi.py (every C function and constant it names must exist in include/alacgpu.h with the same
-// arity) and is exercised with `go vet` / `go test` whenever a toolchain is present (tests/test_go_shim.py).
+// The image this repository is built in has no Go toolchain: THIS FILE HAS NEVER BEEN COMPILED. It is kept in step with
+// the header by tests/test_c_abi.py::test_go_shim_matches_the_header (every C function and constant it names must exist
+// in include/alacgpu.h, and every call must pass as many arguments as the prototype has).
 package alac
 
 /*
@@ -133,6 +133,22 @@ func statusErr(st int32) error {
 func (d *GPUPacketDecoder) DecodePacket(packet []byte) ([]byte, error) {
 	out := make([]byte, int(C.alacgpu_frame_bytes(d.h)))
 
+	n, err := d.DecodePacketInto(packet, out)
+	if err != nil {
+		return nil, err
+	}
+
+	return out[:n], nil
+}
+
+// DecodePacketInto mirrors decodePacketInto (decoder.go:133), the entry Decoder.Read uses (decode.go:179): the PCM goes
+// into the caller's buffer, which must hold a full frame (decoder.go:131-132); nothing is allocated. Returns the
+// number of bytes written.
+func (d *GPUPacketDecoder) DecodePacketInto(packet, out []byte) (int, error) {
+	if len(out) < int(C.alacgpu_frame_bytes(d.h)) {
+		return 0, fmt.Errorf("alacgpu: output buffer of %d bytes, a frame needs %d", len(out), int(C.alacgpu_frame_bytes(d.h)))
+	}
+
 	var (
 		n  C.size_t
 		st C.int32_t
@@ -146,16 +162,18 @@ func (d *GPUPacketDecoder) DecodePacket(packet []byte) ([]byte, error) {
 	switch rc := C.alacgpu_decode_packet(d.h, p, C.size_t(len(packet)),
 		(*C.uint8_t)(unsafe.Pointer(&out[0])), C.size_t(len(out)), &n, &st); rc {
 	case C.ALACGPU_E_OK:
-		return out[:int(n)], nil
+		return int(n), nil
 	case C.ALACGPU_E_DECODE:
-		return nil, statusErr(int32(st))
+		return 0, statusErr(int32(st))
 	default:
-		return nil, fmt.Errorf("alacgpu: %s", C.GoString(C.alacgpu_last_error()))
+		return 0, fmt.Errorf("alacgpu: %s", C.GoString(C.alacgpu_last_error()))
 	}
 }
 
 // DecodePackets is the new batch entry: packets[i] -> pcm[i] (nil and errs[i] on a per-packet failure).
-// The packets go to the device back to back, as they would lie in an mdat; the library needs no padding.
+// The packets are copied back to back into one host blob (one copy of every packet on the host: callers that hold
+// an mdat should use DecodeSamples, which copies nothing) and go to the device as they would lie in an mdat; the
+// library needs no padding.
 func (d *GPUPacketDecoder) DecodePackets(packets [][]byte) (pcm [][]byte, errs []error, err error) {
 	count := len(packets)
 	if count == 0 {
@@ -182,7 +200,7 @@ func (d *GPUPacketDecoder) DecodePackets(packets [][]byte) (pcm [][]byte, errs [
 	frames := make([]C.uint32_t, count)
 	status := make([]C.int32_t, count)
 
-	if rc := C.alacgpu_decode_batch(d.h, (*C.uint8_t)(unsafe.Pointer(&blob[0])), &offsets[0], C.size_t(count),
+	if rc := C.alacgpu_decode_batch(d.h, (*C.uint8_t)(unsafe.Pointer(&blob[0])), C.size_t(total), &offsets[0], C.size_t(count),
 		(*C.uint8_t)(unsafe.Pointer(&out[0])), C.size_t(stride), &frames[0], &status[0]); rc != C.ALACGPU_E_OK {
 		return nil, nil, fmt.Errorf("alacgpu: %s", C.GoString(C.alacgpu_last_error()))
 	}
@@ -204,9 +222,11 @@ func (d *GPUPacketDecoder) DecodePackets(packets [][]byte) (pcm [][]byte, errs [
 	return pcm, errs, nil
 }
 
-// DecodeSamples decodes a whole sample table in one call: mdat is the file region that holds the packets,
-// offsets[i] / sizes[i] locate packet i inside it (internal/mp4 SampleInfo, mp4.go:29-32, rebased to mdat).
-// Nothing is copied on the host: the region goes to the device as it is.
+// DecodeSamples decodes a whole sample table in one call: mdat is the file region that holds the packets, packet i is
+// mdat[offsets[i]:offsets[i+1]] (len(offsets) = packets + 1; internal/mp4 SampleInfo, mp4.go:29-32, rebased to mdat,
+// for a contiguous run of samples). Nothing is copied on the host: the region goes to the device as it is. The table
+// is not trusted: the library checks every descriptor against len(mdat) and reports ALACGPU_ERR_RANGE (ErrRange) in
+// status[i] for a packet that leaves it, without reading it.
 func (d *GPUPacketDecoder) DecodeSamples(mdat []byte, offsets []uint64) (pcm []byte, frames []uint32, status []int32, err error) {
 	count := len(offsets) - 1
 	if count <= 0 {
@@ -223,7 +243,7 @@ func (d *GPUPacketDecoder) DecodeSamples(mdat []byte, offsets []uint64) (pcm []b
 		p = (*C.uint8_t)(unsafe.Pointer(&mdat[0]))
 	}
 
-	if rc := C.alacgpu_decode_batch(d.h, p, (*C.uint64_t)(unsafe.Pointer(&offsets[0])), C.size_t(count),
+	if rc := C.alacgpu_decode_batch(d.h, p, C.size_t(len(mdat)), (*C.uint64_t)(unsafe.Pointer(&offsets[0])), C.size_t(count),
 		(*C.uint8_t)(unsafe.Pointer(&pcm[0])), C.size_t(stride), (*C.uint32_t)(unsafe.Pointer(&frames[0])),
 		(*C.int32_t)(unsafe.Pointer(&status[0]))); rc != C.ALACGPU_E_OK {
 		return nil, nil, nil, fmt.Errorf("alacgpu: %s", C.GoString(C.alacgpu_last_error()))

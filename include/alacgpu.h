@@ -140,8 +140,11 @@ int alacgpu_decode_packet(alacgpu_decoder* dec, const uint8_t* packet, size_t pa
  * the device as they are. Pageable memory is staged through pinned buffers by a few copy threads
  * (ALACGPU_COPY_THREADS); blob / out / frames_out / status that the caller allocated with hipHostMalloc or registered
  * with hipHostRegister are transferred in place. Blocking: returns when everything is in the caller's buffers.
+ * blob_bytes = readable bytes at blob. The offsets are untrusted (a sample table from a file, internal/mp4/mp4.go:382-420):
+ * a packet that does not lie inside [0, blob_bytes), or that ends before it starts, is never read and gets status
+ * ALACGPU_ERR_RANGE, like in the device entry (alacgpu 0.4: the argument is new; 0.3 read whatever the offsets named).
  */
-int alacgpu_decode_batch(alacgpu_decoder* dec, const uint8_t* blob, const uint64_t* offsets,
+int alacgpu_decode_batch(alacgpu_decoder* dec, const uint8_t* blob, size_t blob_bytes, const uint64_t* offsets,
                          size_t n_packets, uint8_t* out, size_t out_stride,
                          uint32_t* frames_out, int32_t* status);
 

@@ -21,11 +21,17 @@
  * reports ALACGPU_ERR_MALFORMED: the reference has no defined result there. The model is a
  * FRESH PacketDecoder per packet (cap(bits.Buf) == len(packet)+4, bitbuffer.go:36-51).
  *
- * PARITY PIN: the reference ships no golden vectors and cannot be built here (Go, no
- * toolchain). This oracle is pinned by the four hand-derived known-answer packets of
- * SURVEY.md §8(c) (tests/golden/kat.json) and by the lossless round trip
- * decode(encode(pcm)) == pcm, the same property the reference's conformance test asserts
- * (tests/conformance_test.go:282-291).
+ * PARITY UNPINNED by the reference itself: it ships no golden vectors and cannot be built here (Go,
+ * no toolchain), so nothing below has been compared with the Go binary. What pins this oracle
+ * instead: the hand-derived known-answer packets K1-K4 of SURVEY.md §8(c) (tests/golden/kat.json),
+ * K5-K13 (tests/golden/kat2.json) and K14-K19 (tests/golden/kat3.json), each decoded on paper from the
+ * reference source in tests/golden/kat_derivation.md; a second, independent restatement in Python
+ * (oracle/goref.py) that agrees with it on ~20 000 valid and corrupted packets
+ * (tests/golden/crosscheck_goref.py); and the lossless round trip decode(encode(pcm)) == pcm, the
+ * property the reference's conformance test asserts (tests/conformance_test.go:282-291).
+ *
+ * TEST INFRASTRUCTURE ONLY: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg are the
+ * only callers; the product (libalacgpu.so, the Python / C++ / Go hosts) never links or loads it.
  */
 #include "alac_oracle.h"
 

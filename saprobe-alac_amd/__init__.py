@@ -193,8 +193,9 @@ _EXPORTS = {
     "alacgpu_decode_packet": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                              ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
                                              ctypes.POINTER(ctypes.c_int32)]),
-    "alacgpu_decode_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
-                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "alacgpu_decode_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                            ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                            ctypes.c_void_p]),
     "alacgpu_decode_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
@@ -327,7 +328,8 @@ class PacketDecoder:
         return res
 
     def decode_batch(self, blob, offsets, out_stride=None):
-        """alacgpu_decode_batch: host blob + offsets[n+1] -> (out[n, stride] uint8, frames, status)."""
+        """alacgpu_decode_batch: host blob + offsets[n+1] -> (out[n, stride] uint8, frames, status). The offsets may
+        come from an untrusted sample table: packets that leave the blob get ALACGPU_ERR_RANGE and are never read."""
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
@@ -336,8 +338,8 @@ class PacketDecoder:
         frames = np.zeros(max(n, 0), dtype=np.uint32)
         status = np.zeros(max(n, 0), dtype=np.int32)
         if n > 0:
-            _check(self._lib.alacgpu_decode_batch(self._h, blob.ctypes.data, offsets.ctypes.data, n, out.ctypes.data,
-                                                  stride, frames.ctypes.data, status.ctypes.data))
+            _check(self._lib.alacgpu_decode_batch(self._h, blob.ctypes.data, blob.size, offsets.ctypes.data, n,
+                                                  out.ctypes.data, stride, frames.ctypes.data, status.ctypes.data))
         return out, frames, status
 
     def decode_batch_device(self, d_blob, blob_bytes, d_offsets, d_sizes, n, d_out, out_stride, d_frames, d_status,

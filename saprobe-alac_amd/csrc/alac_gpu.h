@@ -156,7 +156,7 @@ constexpr uint32_t kRingStride = kRingDw + 4;               /* rows stay 16-byte
 /* device-side launch plan, rebuilt by every decode */
 /* sort keys: 0..2047 regular packets (numU*32 + numV + KEY_WIDE, alac_regular.h); 2048 / 2049 irregular packets
  * (below). A workgroup holds packets of ONE key. */
-constexpr uint32_t kKeys = alac::KEY_IRREGULAR + alac::NUM_CLASSES;
+constexpr uint32_t kKeys = alac::KEY_IRREGULAR + 2u;
 constexpr uint32_t kKeyLegacy = alac::KEY_IRREGULAR;     /* decode_wave */
 constexpr uint32_t kKeyScan = alac::KEY_IRREGULAR + 1u;  /* decode_wave<SCAN> + split pipeline */
 struct Plan {

@@ -51,9 +51,6 @@ struct DevCfg {
     uint32_t aligned16; /* PCM base and stride are multiples of 16: the LDS stager may be used */
 };
 
-/* predictor-order classes (see classify_orders) */
-enum { CLASS_NA4 = 0, CLASS_NA6 = 1, CLASS_NA8 = 2, CLASS_NA16 = 3, NUM_CLASSES = 4 };
-
 /* channelLayoutOffsets (decoder.go:55-64) packed 4 bits per entry, entry k at bits 4k */
 ALAC_DEV uint32_t layout_offset(uint32_t num_chan, uint32_t chan_idx) {
     const uint32_t tbl[8] = {0x0u, 0x10u, 0x102u, 0x3102u, 0x43102u, 0x354102u, 0x3654102u, 0x35410762u};
@@ -207,41 +204,6 @@ ALAC_DEV void store_le(uint8_t* dst, int32_t v, uint32_t bps) {
 /* Orders the unrolled reference predictors handle with int32 coefficients (predictor.go:81-93); every
  * other order takes unpcBlockGeneral and wraps its coefficients to int16 at each update (:664,:675). */
 ALAC_DEV bool order_wraps16(uint32_t na) { return !(na == 4 || na == 5 || na == 6 || na == 8); }
-
-/* Class of a (numU, numV) pair: the smallest register-tap width whose kernel variant runs both channels on
- * the fast path. 0 / 31 need no taps. Orders that wrap (1,2,3,7,9..16) go to the NA16 variant, the only one
- * compiled with the per-lane int16 wrap. Orders 17..30 exist only on paper; they run on the scratch
- * fall-back of whatever class the other channel picks. */
-ALAC_DEV uint32_t classify_orders(uint32_t nu, uint32_t nv) {
-    uint32_t c = CLASS_NA4;
-    for (int t = 0; t < 2; ++t) {
-        const uint32_t na = t ? nv : nu;
-        uint32_t k;
-        if (na == 0 || na == 31 || na == 4) k = CLASS_NA4;
-        else if (na == 5 || na == 6) k = CLASS_NA6;
-        else if (na == 8) k = CLASS_NA8;
-        else if (na <= 16) k = CLASS_NA16;
-        else k = CLASS_NA4;
-        c = k > c ? k : c;
-    }
-    return c;
-}
-
-/* First element's predictor orders without decoding anything (the sort key). Packets that start with
- * DSE/FIL/END, an escape element or garbage get class NA4: any class is correct for any packet. */
-ALAC_DEV uint32_t classify_packet(const uint8_t* pkt, uint32_t size, uint32_t avail) {
-    const Bits bits{pkt, size, avail};
-    if (size < 8) return CLASS_NA4;
-    const uint32_t tag = bits.get(0, 3);
-    if (!(tag == 0 || tag == 1 || tag == 3)) return CLASS_NA4;
-    const uint32_t hdr = bits.get(19, 4);
-    if (hdr & 1u) return CLASS_NA4;
-    uint32_t pos = 23u + ((hdr >> 3) ? 32u : 0u) + 16u;
-    const uint32_t nu = bits.get(pos + 11, 5);
-    uint32_t nv = 0;
-    if (tag == 1) nv = bits.get(pos + 16u + 16u * nu + 11u, 5);
-    return classify_orders(nu, nv);
-}
 
 /* ---- descriptors of the split pipeline (alac_split.h): written by the scan pass, one per bitstream channel ---- */
 struct ChanDesc {

@@ -188,6 +188,7 @@ struct Slot {
     hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
     size_t first = 0, n = 0;
     bool busy = false;
+    bool bad = false; /* the chunk holds descriptors that leave the blob (ALACGPU_ERR_RANGE, set on the way back) */
 };
 
 } /* namespace */
@@ -573,13 +574,15 @@ int alacgpu_decode_batch_device(alacgpu_decoder* d, const uint8_t* d_blob, size_
 /*
  * DecodePackets from host memory: the batch is cut into chunks of whole packets; chunk c is uploaded on one stream
  * while chunk c-1 decodes on the handle's stream and chunk c-2 comes back on a third. The packets go up exactly as
- * they lie in the caller's blob (no re-pack: the kernels read dense blobs), together with their offsets, in ONE
- * transfer; PCM, frame counts and status words come back in ONE. Pageable caller memory is staged through pinned
+ * they lie in the caller's blob (no re-pack: the kernels read dense blobs), together with their offsets and sizes, in
+ * ONE transfer; PCM, frame counts and status words come back in ONE. Pageable caller memory is staged through pinned
  * buffers by a few copy threads; memory the caller pinned itself (hipHostMalloc / hipHostRegister) is used in place.
+ * The offsets are untrusted (a sample table read from a file): a packet that does not lie inside [0, blob_bytes), or
+ * whose end lies before its start, is never read; it gets ALACGPU_ERR_RANGE like in the device entry.
  */
-int alacgpu_decode_batch(alacgpu_decoder* d, const uint8_t* blob, const uint64_t* offsets, size_t n, uint8_t* out,
-                         size_t out_stride, uint32_t* frames_out, int32_t* status) {
-    if (!d || (n && (!offsets || !out || !frames_out || !status))) {
+int alacgpu_decode_batch(alacgpu_decoder* d, const uint8_t* blob, size_t blob_bytes, const uint64_t* offsets, size_t n,
+                         uint8_t* out, size_t out_stride, uint32_t* frames_out, int32_t* status) {
+    if (!d || (n && (!offsets || !out || !frames_out || !status)) || (blob_bytes && !blob)) {
         set_err("null argument");
         return ALACGPU_E_ARG;
     }
@@ -588,21 +591,15 @@ int alacgpu_decode_batch(alacgpu_decoder* d, const uint8_t* blob, const uint64_t
         return ALACGPU_E_ARG;
     }
     if (n == 0) return ALACGPU_E_OK;
-    for (size_t i = 0; i < n; i++) {
-        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 0x0fffffffull) {
-            set_err("bad offsets at packet %zu", i);
-            return ALACGPU_E_ARG;
-        }
-    }
-    if (offsets[n] > offsets[0] && !blob) {
-        set_err("null argument");
-        return ALACGPU_E_ARG;
-    }
+    auto valid = [&](size_t i) {
+        const uint64_t lo = offsets[i], hi = offsets[i + 1];
+        return lo <= hi && hi <= (uint64_t)blob_bytes && hi - lo <= 0x0fffffffull;
+    };
     HIP_TRY(hipSetDevice(d->device));
     const size_t fb = d->frame_bytes;
     const size_t d_stride = (fb + 15u) & ~(size_t)15u; /* 16-byte aligned device rows: the LDS-staged wide stores */
     const bool out_pinned = is_pinned(out) && is_pinned(frames_out) && is_pinned(status);
-    const bool in_pinned = (offsets[n] == offsets[0]) || is_pinned(blob);
+    const bool in_pinned = blob_bytes == 0 || is_pinned(blob);
     if (!d->pool && !(out_pinned && in_pinned)) {
         unsigned t = std::thread::hardware_concurrency();
         t = t > 16 ? 8 : (t > 2 ? t / 2 : 1);
@@ -610,7 +607,9 @@ int alacgpu_decode_batch(alacgpu_decoder* d, const uint8_t* blob, const uint64_t
         d->pool = new (std::nothrow) CopyPool(t - 1); /* the calling thread copies too */
     }
 
-    auto finish = [&](Slot& s) -> int { /* chunk is back in pinned memory (or in place): hand it to the caller */
+    /* chunk is back in pinned memory (or in place): hand it to the caller; descriptors that left the blob get their
+     * status here (the device saw them as empty packets) */
+    auto finish = [&](Slot& s) -> int {
         HIP_TRY(hipEventSynchronize(s.ev_out));
         if (!out_pinned) {
             const uint8_t* h = (const uint8_t*)s.h_out.p;
@@ -629,47 +628,48 @@ int alacgpu_decode_batch(alacgpu_decoder* d, const uint8_t* blob, const uint64_t
             if (d->pool) d->pool->parallel_for(pieces, body);
             else for (size_t k = 0; k < pieces; k++) body(k);
         }
+        if (s.bad)
+            for (size_t i = s.first; i < s.first + s.n; i++)
+                if (!valid(i)) {
+                    status[i] = ALACGPU_ERR_RANGE;
+                    frames_out[i] = 0;
+                }
         s.busy = false;
         return ALACGPU_E_OK;
     };
-
-    size_t first = 0;
-    int turn = 0;
-    int rc = ALACGPU_E_OK;
-    while (first < n && rc == ALACGPU_E_OK) {
-        /* packets of this chunk: whole packets, about chunk_bytes of traffic (packet bytes in + PCM out) */
-        size_t cnt = 0;
-        uint64_t bytes = 0;
-        while (first + cnt < n && (cnt == 0 || bytes < d->chunk_bytes)) {
-            bytes += (offsets[first + cnt + 1] - offsets[first + cnt]) + fb;
-            cnt++;
-        }
-        Slot& s = d->slots[turn];
-        turn = (turn + 1) % kSlots;
-        if (s.busy && (rc = finish(s))) break;
+    /* one chunk: upload, decode, download, all asynchronous; HIP errors come back as a code so that the caller drains */
+    auto submit = [&](Slot& s, size_t first, size_t cnt, uint64_t lo, uint64_t hi) -> int {
+        int rc;
         s.first = first;
         s.n = cnt;
-        const uint64_t b0 = offsets[first], b1 = offsets[first + cnt];
-        const size_t in_bytes = (size_t)(b1 - b0);
-        const size_t meta = (cnt + 1) * sizeof(uint64_t);
+        s.bad = false;
+        const size_t in_bytes = (size_t)(hi - lo);
+        const size_t meta = (cnt + 1) * sizeof(uint64_t) + cnt * sizeof(uint32_t);
         const size_t meta_pad = (meta + 255u) & ~(size_t)255u; /* packet bytes start 256-byte aligned on the device */
-        if ((rc = s.d_in.ensure(meta_pad + in_bytes + 16))) break;
-        if ((rc = s.d_out.ensure(cnt * d_stride + cnt * 8 + 16))) break;
-        if ((rc = s.h_in.ensure(in_pinned ? meta_pad : meta_pad + in_bytes))) break;
-        if (!out_pinned && (rc = s.h_out.ensure(cnt * d_stride + cnt * 8))) break;
-        /* upload: offsets rebased to the chunk's first byte, then the bytes */
+        if ((rc = s.d_in.ensure(meta_pad + in_bytes + 16))) return rc;
+        if ((rc = s.d_out.ensure(cnt * d_stride + cnt * 8 + 16))) return rc;
+        if ((rc = s.h_in.ensure(in_pinned ? meta_pad : meta_pad + in_bytes))) return rc;
+        if (!out_pinned && (rc = s.h_out.ensure(cnt * d_stride + cnt * 8))) return rc;
+        /* upload: offsets rebased to the chunk's first byte and sizes, then the bytes */
         uint64_t* h_off = (uint64_t*)s.h_in.p;
-        for (size_t i = 0; i <= cnt; i++) h_off[i] = offsets[first + i] - b0;
+        uint32_t* h_sz = (uint32_t*)(h_off + cnt + 1);
+        for (size_t i = 0; i < cnt; i++) {
+            const bool ok = valid(first + i);
+            h_off[i] = ok ? offsets[first + i] - lo : 0u;
+            h_sz[i] = ok ? (uint32_t)(offsets[first + i + 1] - offsets[first + i]) : 0u;
+            s.bad = s.bad || !ok;
+        }
+        h_off[cnt] = in_bytes;
         uint8_t* d_in = (uint8_t*)s.d_in.p;
         if (in_pinned) {
             HIP_TRY(hipMemcpyAsync(d_in, h_off, meta, hipMemcpyHostToDevice, d->s_in));
-            if (in_bytes) HIP_TRY(hipMemcpyAsync(d_in + meta_pad, blob + b0, in_bytes, hipMemcpyHostToDevice, d->s_in));
+            if (in_bytes) HIP_TRY(hipMemcpyAsync(d_in + meta_pad, blob + lo, in_bytes, hipMemcpyHostToDevice, d->s_in));
         } else {
             uint8_t* hb = (uint8_t*)s.h_in.p + meta_pad;
             const size_t pieces = std::max<size_t>(1, std::min<size_t>(64, in_bytes >> 20));
             auto body = [&](size_t k) {
-                const size_t lo = in_bytes * k / pieces, hi = in_bytes * (k + 1) / pieces;
-                memcpy(hb + lo, blob + b0 + lo, hi - lo);
+                const size_t a = in_bytes * k / pieces, b = in_bytes * (k + 1) / pieces;
+                memcpy(hb + a, blob + lo + a, b - a);
             };
             if (d->pool) d->pool->parallel_for(pieces, body);
             else for (size_t k = 0; k < pieces; k++) body(k);
@@ -681,7 +681,9 @@ int alacgpu_decode_batch(alacgpu_decoder* d, const uint8_t* blob, const uint64_t
         uint8_t* d_pcm = (uint8_t*)s.d_out.p;
         uint32_t* d_fr = (uint32_t*)(d_pcm + cnt * d_stride);
         int32_t* d_st = (int32_t*)(d_fr + cnt);
-        if ((rc = launch(d, d_in + meta_pad, in_bytes, (const uint64_t*)d_in, nullptr, cnt, d_pcm, d_stride, d_fr, d_st))) break;
+        if ((rc = launch(d, d_in + meta_pad, in_bytes, (const uint64_t*)d_in, (const uint32_t*)(d_in + (cnt + 1) * sizeof(uint64_t)), cnt,
+                         d_pcm, d_stride, d_fr, d_st)))
+            return rc;
         HIP_TRY(hipEventRecord(s.ev_k, d->stream));
         /* download */
         HIP_TRY(hipStreamWaitEvent(d->s_out, s.ev_k, 0));
@@ -694,7 +696,44 @@ int alacgpu_decode_batch(alacgpu_decoder* d, const uint8_t* blob, const uint64_t
         }
         HIP_TRY(hipEventRecord(s.ev_out, d->s_out));
         s.busy = true;
+        return ALACGPU_E_OK;
+    };
+
+    size_t first = 0;
+    int turn = 0;
+    int rc = ALACGPU_E_OK;
+    while (first < n && rc == ALACGPU_E_OK) {
+        /* packets of this chunk: whole packets, about chunk_bytes of traffic (the span of the blob they cover in + PCM
+         * out). With a sane table the span is offsets[first] .. offsets[first + cnt]. */
+        size_t cnt = 0;
+        uint64_t lo = ~0ull, hi = 0;
+        while (first + cnt < n) {
+            uint64_t nlo = lo, nhi = hi;
+            if (valid(first + cnt)) {
+                nlo = std::min(lo, offsets[first + cnt]);
+                nhi = std::max(hi, offsets[first + cnt + 1]);
+            }
+            const uint64_t bytes = (nhi > nlo ? nhi - nlo : 0) + (uint64_t)(cnt + 1) * fb;
+            if (cnt != 0 && bytes > d->chunk_bytes) break;
+            lo = nlo;
+            hi = nhi;
+            cnt++;
+        }
+        if (hi < lo) lo = hi = 0; /* no valid packet in the chunk */
+        Slot& s = d->slots[turn];
+        turn = (turn + 1) % kSlots;
+        if (s.busy && (rc = finish(s))) break;
+        rc = submit(s, first, cnt, lo, hi);
         first += cnt;
+    }
+    if (rc != ALACGPU_E_OK) {
+        /* a step of a chunk failed: nothing of this call may still be writing the caller's buffers when we return, and
+         * no slot may carry a chunk of this call into the next one */
+        (void)hipStreamSynchronize(d->s_in);
+        (void)hipStreamSynchronize(d->stream);
+        (void)hipStreamSynchronize(d->s_out);
+        for (int k = 0; k < kSlots; k++) d->slots[k].busy = false;
+        return rc;
     }
     /* drain, oldest first */
     for (int k = 0; k < kSlots; k++) {
@@ -723,7 +762,7 @@ int alacgpu_decode_packet(alacgpu_decoder* d, const uint8_t* packet, size_t pack
     uint32_t frames = 0;
     int32_t st = 0;
     /* a batch of one through the same entry: one upload (offsets + bytes), the kernels, one download */
-    int rc = alacgpu_decode_batch(d, packet_len ? packet : &dummy, offs, 1, out, d->frame_bytes, &frames, &st);
+    int rc = alacgpu_decode_batch(d, packet_len ? packet : &dummy, packet_len, offs, 1, out, d->frame_bytes, &frames, &st);
     if (rc) return rc;
     if (status_out) *status_out = st;
     if (st != 0) {
@@ -802,6 +841,6 @@ int alacgpu_debug_prof(unsigned long long* out16) {
 }
 #endif
 
-const char* alacgpu_version(void) { return "alacgpu 0.3.0 gfx950"; }
+const char* alacgpu_version(void) { return "alacgpu 0.4.0 gfx950"; }
 
 } /* extern "C" */

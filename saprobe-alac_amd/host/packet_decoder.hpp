@@ -74,11 +74,12 @@ public:
         return out;
     }
 
-    // Batch entry: packet i = blob[offsets[i], offsets[i+1]); PCM i at out + i*out_stride. Per-packet failures are
-    // reported in status[i] (frames[i] = 0) and do not affect the other packets.
-    void DecodePackets(const uint8_t* blob, const uint64_t* offsets, size_t n, uint8_t* out, size_t out_stride,
-                       uint32_t* frames, int32_t* status) {
-        if (alacgpu_decode_batch(h_.get(), blob, offsets, n, out, out_stride, frames, status) != ALACGPU_E_OK)
+    // Batch entry: packet i = blob[offsets[i], offsets[i+1]) of the blob_bytes readable bytes at blob; PCM i at
+    // out + i*out_stride. Per-packet failures are reported in status[i] (frames[i] = 0) and do not affect the other
+    // packets; a packet whose offsets leave the blob is never read (ALACGPU_ERR_RANGE).
+    void DecodePackets(const uint8_t* blob, size_t blob_bytes, const uint64_t* offsets, size_t n, uint8_t* out,
+                       size_t out_stride, uint32_t* frames, int32_t* status) {
+        if (alacgpu_decode_batch(h_.get(), blob, blob_bytes, offsets, n, out, out_stride, frames, status) != ALACGPU_E_OK)
             throw std::runtime_error(alacgpu_last_error());
     }
 

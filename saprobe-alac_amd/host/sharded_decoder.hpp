@@ -38,8 +38,8 @@ public:
     PCMFormat Format() const { return decoders_[0]->Format(); }
 
     // Same contract as PacketDecoder::DecodePackets; slice g is decoded by decoder g on its own thread.
-    void DecodePackets(const uint8_t* blob, const uint64_t* offsets, size_t n, uint8_t* out, size_t out_stride,
-                       uint32_t* frames, int32_t* status) {
+    void DecodePackets(const uint8_t* blob, size_t blob_bytes, const uint64_t* offsets, size_t n, uint8_t* out,
+                       size_t out_stride, uint32_t* frames, int32_t* status) {
         const size_t G = decoders_.size();
         std::vector<std::exception_ptr> errs(G);
         std::vector<std::thread> threads;
@@ -48,11 +48,9 @@ public:
                 try {
                     const auto r = ShardRange(n, G, g);
                     if (r.first == r.second) return;
-                    // the slice's packets lie at blob + offsets[lo] ...: rebase the offsets, not the bytes
-                    std::vector<uint64_t> sub(offsets + r.first, offsets + r.second + 1);
-                    const uint64_t b0 = sub[0];
-                    for (auto& o : sub) o -= b0;
-                    decoders_[g]->DecodePackets(blob + b0, sub.data(), r.second - r.first, out + r.first * out_stride,
+                    // every slice names its packets in the caller's blob (the host entry uploads only the span of the
+                    // blob its packets cover, and checks every descriptor against blob_bytes)
+                    decoders_[g]->DecodePackets(blob, blob_bytes, offsets + r.first, r.second - r.first, out + r.first * out_stride,
                                                 out_stride, frames + r.first, status + r.first);
                 } catch (...) {
                     errs[g] = std::current_exception();

@@ -113,7 +113,7 @@ private:
         size_t last = std::min(first + window_, Packets());
         lost_ = SIZE_MAX;
         for (size_t k = first; k < last; ++k)
-            if (track_.offsets[k] + track_.sizes[k] > len_) {
+            if (track_.offsets[k] > len_ || track_.sizes[k] > len_ - track_.offsets[k]) {
                 lost_ = k;
                 last = k;
                 break;
@@ -124,18 +124,23 @@ private:
         bool run = true;
         for (size_t k = 1; k < n && run; ++k) run = track_.offsets[first + k] == track_.offsets[first + k - 1] + track_.sizes[first + k - 1];
         const uint8_t* blob = n ? file_ + track_.offsets[first] : nullptr;  // one mdat run: no gather
+        size_t blob_bytes = n ? (size_t)(len_ - track_.offsets[first]) : 0;
         if (!run) {
             gather_.resize(starts_[n] + 1);
             for (size_t k = 0; k < n; ++k) memcpy(gather_.data() + starts_[k], file_ + track_.offsets[first + k], track_.sizes[first + k]);
             blob = gather_.data();
+            blob_bytes = (size_t)starts_[n];
         }
         if (n) {
             static const uint8_t none = 0;
-            if (starts_[n] == 0) blob = &none;
+            if (starts_[n] == 0) {
+                blob = &none;
+                blob_bytes = 0;
+            }
             out_.resize(n * stride_);
             frames_.resize(n);
             status_.resize(n);
-            dec_->DecodePackets(blob, starts_.data(), n, out_.data(), stride_, frames_.data(), status_.data());
+            dec_->DecodePackets(blob, blob_bytes, starts_.data(), n, out_.data(), stride_, frames_.data(), status_.data());
         }
         w0_ = first;
         w1_ = last;

@@ -62,8 +62,9 @@ class ShardedDecoder:
         def work(g):
             try:
                 lo, hi = shard_range(n, world, g)
-                sub = offsets[lo:hi + 1] - offsets[lo]
-                results[g] = self.decoders[g].decode_batch(blob[int(offsets[lo]):max(int(offsets[hi]), int(offsets[lo]) + 1)], sub)
+                # every slice names its packets in the caller's blob: the host entry uploads only the span its packets
+                # cover and checks every descriptor against the blob's length (ALACGPU_ERR_RANGE)
+                results[g] = self.decoders[g].decode_batch(blob, offsets[lo:hi + 1])
             except Exception as e:  # noqa: BLE001
                 errors.append(e)
 

@@ -121,7 +121,7 @@ int main(int argc, char** argv) {
         offsets[1] = plen;
         offsets[2] = plen + plen / 2;
         offsets[3] = 2 * plen + plen / 2;
-        if (alacgpu_decode_batch(dec, blob, offsets, 3, bout, fb, frames, status) != ALACGPU_E_OK) {
+        if (alacgpu_decode_batch(dec, blob, (size_t)(2 * plen + plen / 2), offsets, 3, bout, fb, frames, status) != ALACGPU_E_OK) {
             fprintf(stderr, "%s: decode_batch: %s\n", kats[k].name, alacgpu_last_error());
             return 1;
         }

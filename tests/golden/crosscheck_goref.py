@@ -1,4 +1,4 @@
-"""Cross-check of the two CPU restatements of the reference: oracle/alac_oracle.c (C, round 1) against tests/goref.py
+"""Cross-check of the two CPU restatements of the reference: oracle/alac_oracle.c (C, round 1) against oracle/goref.py
 (pure Python, round 2, written from the Go source without consulting the C file).
 
     python tests/golden/crosscheck_goref.py [--packets 10000] [--seed N]
@@ -26,7 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import goref  # noqa: E402
+from oracle import goref  # noqa: E402
 from conftest import mutate_packets  # noqa: E402
 from oracle import oracle  # noqa: E402
 

@@ -62,11 +62,11 @@ long long shim_position(void* d) { return static_cast<alac::Decoder*>(d)->Positi
 
 /* host/sharded_decoder.hpp: one handle + one host thread per entry of devices[] */
 long shim_sharded_decode(const alacgpu_config* cfg, const int* devices, size_t n_devices, const uint8_t* blob,
-                         const uint64_t* offsets, size_t n, uint8_t* out, size_t out_stride, uint32_t* frames,
+                         size_t blob_bytes, const uint64_t* offsets, size_t n, uint8_t* out, size_t out_stride, uint32_t* frames,
                          int32_t* status) {
     SHIM_TRY({
         alac::ShardedDecoder dec(*cfg, std::vector<int>(devices, devices + n_devices));
-        dec.DecodePackets(blob, offsets, n, out, out_stride, frames, status);
+        dec.DecodePackets(blob, blob_bytes, offsets, n, out, out_stride, frames, status);
     });
     return 0;
 }

@@ -207,10 +207,10 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
         }
         const uint32_t cls = variant >= 0 ? (uint32_t)variant : 3u;
         if (classes_out && variant >= 0) classes_out[i] = 1024u + cls;
-        switch (cls) {
-            case alac::CLASS_NA4: status[i] = alac::decode_wave<HostWave, 4, false>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i]); break;
-            case alac::CLASS_NA6: status[i] = alac::decode_wave<HostWave, 6, false>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i]); break;
-            case alac::CLASS_NA8: status[i] = alac::decode_wave<HostWave, 8, false>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i]); break;
+        switch (cls) { /* register-tap widths of the whole-packet decoder: 4, 6, 8, or 16 with the int16 wrap */
+            case 0: status[i] = alac::decode_wave<HostWave, 4, false>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i]); break;
+            case 1: status[i] = alac::decode_wave<HostWave, 6, false>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i]); break;
+            case 2: status[i] = alac::decode_wave<HostWave, 8, false>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i]); break;
             default: status[i] = alac::decode_wave<HostWave, 16, true>(wv, dc, true, p, sizes[i], avail, o, &frames_out[i]); break;
         }
     }

@@ -1,4 +1,4 @@
-"""tests/goref.py (the pure-Python transliteration of the reference, written independently of the C oracle) against
+"""oracle/goref.py (the pure-Python transliteration of the reference, written independently of the C oracle) against
 the committed vectors, the hand-derived KATs and the C oracle on seeded random packets. Four readings of the
 reference — oracle, goref, hand derivations, HIP kernels — must agree; this file covers the first three on the CPU
 (`tests/golden/crosscheck_goref.py` runs the same comparison over 10 000+ packets)."""
@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-import goref
+from oracle import goref
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -243,7 +243,7 @@ def test_host_entry_many_chunks(pkg, oracle, synth, helpers, gpu_decoder_factory
         t_out = torch.empty((b.n, dec.frame_bytes), dtype=torch.uint8, pin_memory=True)
         t_fr = torch.empty(b.n, dtype=torch.int32, pin_memory=True)
         t_st = torch.empty(b.n, dtype=torch.int32, pin_memory=True)
-        pkg._check(dec._lib.alacgpu_decode_batch(dec._h, t_blob.data_ptr(), offs1.ctypes.data, b.n, t_out.data_ptr(),
+        pkg._check(dec._lib.alacgpu_decode_batch(dec._h, t_blob.data_ptr(), len(blob), offs1.ctypes.data, b.n, t_out.data_ptr(),
                                                  dec.frame_bytes, t_fr.data_ptr(), t_st.data_ptr()))
         got = (t_out.numpy(), t_fr.numpy().view(np.uint32), t_st.numpy())
         helpers.assert_same_decode(cfg, ref, got, 4, "pinned")
@@ -383,3 +383,134 @@ def test_gated_pairs_with_corrupt_packets_and_two_handles_at_once(pkg, synth, or
     for k in range(2):
         helpers.assert_same_decode(cfg, ref, results[k], 4, "handle %d" % k)
     assert all(gated)  # the batch really went through alac_decode_16g
+
+
+def test_host_entry_checks_untrusted_offsets(pkg, oracle, synth, helpers, gpu_decoder_factory, monkeypatch):
+    """alacgpu_decode_batch takes its offsets from a sample table (internal/mp4/mp4.go:382-420: stco / stsz of a file
+    nobody vouches for). Descriptors that leave the blob, or end before they start, must never be read: they get
+    ALACGPU_ERR_RANGE, the packets around them decode as if nothing had happened. Small chunks, so that bad descriptors
+    fall on chunk borders too; the blob sits at the end of its allocation in pageable and in pinned memory."""
+    import torch
+    cfg = oracle.make_config(256, 16, 2)
+    b = synth.gen_batch(cfg, 600, threads=8)
+    ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=8)
+    blob, offs, sizes = helpers.pack_dense([b.packet(i) for i in range(b.n)])
+    offs1 = np.concatenate([offs, [np.uint64(len(blob))]]).astype(np.uint64)
+    rng = np.random.default_rng(7)
+    bad = offs1.copy()
+    big = np.uint64(len(blob))
+    # a table whose tail runs past the file, entries far outside, an entry that ends before it starts
+    bad[590:] += np.uint64(3 * len(blob))
+    for i in rng.choice(np.arange(5, 580), 40, replace=False):
+        bad[i] = [big + np.uint64(1), np.uint64(2**63), np.uint64(2**64 - 1), bad[i - 1] - np.uint64(1) if bad[i - 1] else big * np.uint64(2)][int(rng.integers(0, 4))]
+    lo, hi = bad[:-1], bad[1:]
+    ok = (lo <= hi) & (hi <= big)
+    assert 0 < (~ok).sum() < 200 and ok.sum() > 300
+    # a good packet is one whose bytes are still exactly its own (both ends untouched)
+    same = ok & (lo == offs1[:-1]) & (hi == offs1[1:])
+    monkeypatch.setenv("ALACGPU_CHUNK_MB", "1")
+    with gpu_decoder_factory(cfg) as dec:
+        for pinned in (False, True):
+            if pinned:
+                t_blob = torch.empty(len(blob), dtype=torch.uint8, pin_memory=True)
+                t_blob.numpy()[:] = blob
+                hb = t_blob.numpy()
+            else:
+                hb = blob
+            out, fr, st = dec.decode_batch(hb, bad)
+            assert (st[~ok] == 7).all() and (fr[~ok] == 0).all(), "pinned %s" % pinned  # ALACGPU_ERR_RANGE
+            got = (out[same], fr[same], st[same])
+            want = (ref[0][same], ref[1][same], ref[2][same])
+            helpers.assert_same_decode(cfg, want, got, 4, "pinned %s" % pinned)
+            assert (st[ok] != 7).all()
+        # and the handle is as good as new afterwards
+        helpers.assert_same_decode(cfg, ref, dec.decode_batch(blob, offs1), 4, "after")
+
+
+def test_decode_packet_in_the_shape_of_baseline_config_a(pkg, oracle, synth, gpu_decoder_factory):
+    """BASELINE config a: PacketDecoder.DecodePacket (decoder.go:117) on ONE 16-bit / 44.1 kHz stereo packet of 4096
+    frames — a batch of one through the same kernels — against the oracle, for a handful of packets of every
+    signal profile (the reference reaches this call from Decoder.Read, decode.go:179)."""
+    cfg = oracle.make_config(4096, 16, 2)
+    pc = pkg.PacketConfig(FrameLength=4096, BitDepth=16, NumChannels=2)
+    with pkg.NewPacketDecoder(pc) as dec:
+        assert dec.Format().SampleRate == 44100
+        for prof in (synth.PROFILE_MUSIC, synth.PROFILE_QUIET, synth.PROFILE_NOISE, synth.PROFILE_STRESS):
+            b = synth.gen_batch(cfg, 6, profile=prof, threads=4)
+            ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=4)
+            for i in range(b.n):
+                try:
+                    pcm, st = dec.DecodePacket(b.packet(i)), 0
+                except pkg.ErrDecode as e:
+                    pcm, st = b"", e.status
+                assert st == int(ref[2][i]), (prof, i)
+                if st == 0:
+                    assert len(pcm) == int(ref[1][i]) * 4
+                    assert pcm == ref[0][i, :len(pcm)].tobytes(), (prof, i)
+                    if prof != synth.PROFILE_STRESS:  # lossless (tests/conformance_test.go:282-291)
+                        assert pcm == b.pcm[i, :len(pcm)].tobytes()
+
+
+@pytest.mark.parametrize("depth,ch,fl", [(24, 2, 4096), (32, 1, 4096), (32, 2, 1024), (24, 1, 700)])
+def test_wide_channels_on_the_wave_pair(pkg, oracle, synth, helpers, lane_sim, gpu_decoder_factory, depth, ch, fl):
+    """24- and 32-bit streams WITHOUT shift bytes have chanBits 24..33 (decoder.go:371): the literal 32-bit predictor
+    (predictor.go:46 with its wrapping products), sorted under the wide keys and decoded by alac_decode_w24 / _w32.
+    NOSHIFT: every element without shift bytes; MIXED: independent predictor orders per channel (many sort keys)."""
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    with gpu_decoder_factory(cfg) as dec:
+        for prof, n in ((synth.PROFILE_MUSIC_NOSHIFT, 300), (synth.PROFILE_MUSIC_MIXED, 400)):
+            b = synth.gen_batch(cfg, n, profile=prof, threads=8)
+            ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=8)
+            assert (ref[2] == 0).all()
+            got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
+            helpers.assert_same_decode(cfg, ref, got, bpf, "profile %d" % prof)
+            if not (depth == 32 and ch == 2):  # 32-bit pairs without shift bytes: chanBits 33, every sample 0 (predictor.go:46)
+                for i in range(b.n):
+                    nb = int(b.frames[i]) * bpf
+                    assert np.array_equal(got[0][i, :nb], b.pcm[i, :nb])
+            # these packets are sorted under the wide keys (the classifier is the kernel's own code, built for the host),
+            # which only alac_decode_w24 / _w32 decode
+            keys = lane_sim(cfg, b.blob, b.offsets, b.sizes, variant=-1, want_classes=True)[3]
+            wide = (keys >= 1024) & (keys < 2048)
+            if prof == synth.PROFILE_MUSIC_NOSHIFT:
+                assert wide.sum() > n // 2, "no wide keys"
+            else:  # independent predictor orders per channel: many keys, i.e. many partly filled waves
+                assert len(np.unique(keys[keys < 2048])) >= (6 if ch == 2 else 3)
+
+
+def test_gated_pairs_on_full_length_packets(pkg, synth, oracle, helpers, gpu_decoder_factory):
+    """70 000 x 16-bit stereo packets of 4096 frames: between four and five pairs per CU, the gated kernel's case, at
+    the benchmark's frame length (the other gated tests use short frames). Checked by decode(encode(pcm)) == pcm over
+    the whole batch and against the oracle on two slices."""
+    import torch
+    n, fl = 70000, 4096
+    cfg = oracle.make_config(fl, 16, 2)
+    b = synth.gen_batch(cfg, n, threads=16)
+    dev = torch.device("cuda:0")
+    stride = fl * 4
+    d_blob = torch.from_numpy(b.blob).to(dev)
+    d_off = torch.from_numpy(b.offsets.astype(np.int64)).to(dev)
+    d_sz = torch.from_numpy(b.sizes.astype(np.int32)).to(dev)
+    d_out = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    d_fr = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with gpu_decoder_factory(cfg) as dec:
+        dec.decode_batch_device(d_blob.data_ptr(), d_blob.numel(), d_off.data_ptr(), d_sz.data_ptr(), n, d_out.data_ptr(),
+                                stride, d_fr.data_ptr(), d_st.data_ptr(), sync=True)
+        place = dec.pair_placement()
+    assert int(d_st.abs().sum()) == 0
+    assert np.array_equal(d_fr.cpu().numpy().astype(np.uint32), b.frames)
+    for lo in range(0, n, 8192):
+        exp = torch.from_numpy(b.pcm[lo:lo + 8192]).to(dev)
+        assert torch.equal(d_out[lo:lo + 8192], exp), lo
+        del exp
+    for lo in (0, n - 200):
+        ref = oracle.decode_batch(cfg, b.blob, b.offsets[lo:lo + 200], b.sizes[lo:lo + 200], threads=8)
+        assert np.array_equal(ref[0], d_out[lo:lo + 200].cpu().numpy())
+    tags = place[:, 0]
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    if 4 * n_cu < len(tags) <= 6 * n_cu:
+        owned = tags[tags != 0]
+        assert len(owned) >= len(tags) - 24 and (owned >> 31).all()

@@ -81,7 +81,7 @@ def test_handles_share_nothing_across_threads(pkg, oracle, synth, helpers):
                     full = b.frames == cfg.frame_length
                     assert np.array_equal(out[full], b.pcm[full]), "thread %d round %d" % (i, r)
                     if i == 0:  # a call that fails on this thread only
-                        rc = dec._lib.alacgpu_decode_batch(dec._h, None, None, 5, None, 0, None, None)
+                        rc = dec._lib.alacgpu_decode_batch(dec._h, None, 0, None, 5, None, 0, None, None)
                         assert rc == -2 and b"null" in dec._lib.alacgpu_last_error()
                     else:
                         assert dec._lib.alacgpu_last_error() in (b"", None) or b"null" not in dec._lib.alacgpu_last_error()
@@ -118,7 +118,7 @@ def test_cpp_sharded_decoder(pkg, oracle, synth, helpers):
         d = (ctypes.c_int * len(devs))(*devs)
         L.shim_sharded_decode.restype = ctypes.c_long
         rc = L.shim_sharded_decode(ctypes.byref(pcfg), d, ctypes.c_size_t(len(devs)), ctypes.c_void_p(blob.ctypes.data),
-                                   ctypes.c_void_p(offs.ctypes.data), ctypes.c_size_t(b.n), ctypes.c_void_p(out.ctypes.data),
+                                   ctypes.c_size_t(len(blob)), ctypes.c_void_p(offs.ctypes.data), ctypes.c_size_t(b.n), ctypes.c_void_p(out.ctypes.data),
                                    ctypes.c_size_t(stride), ctypes.c_void_p(fr.ctypes.data), ctypes.c_void_p(st.ctypes.data))
         assert rc == 0, L.shim_last_error()
         helpers.assert_same_decode(cfg, ref, (out, fr, st), 4, "devices %s" % devs)
