@@ -1,4 +1,4 @@
-"""Assembles the hand-built known-answer packets K5..K13 into tests/golden/kat2.json.
+"""Assembles the hand-built known-answer packets K5..K13 into tests/golden/kat2.json and K14..K19 into kat3.json.
 
 This script only PACKS BITS: every field below was chosen by hand, every expected PCM byte string was worked out on
 paper from the reference source (tests/golden/kat_derivation.md holds the derivations, step by step, with the reference
@@ -6,7 +6,7 @@ lines they follow) and is typed in here as a constant. Nothing in this file deco
 goref, kernel) was used to produce the expectations. tests/test_oracle.py, tests/test_goref.py and
 tests/test_gpu_parity.py then require the C oracle, the Python transliteration and the HIP kernels to reproduce them.
 
-    python tests/golden/kat_build.py        # rewrites kat2.json
+    python tests/golden/kat_build.py        # rewrites kat2.json and kat3.json
 """
 import json
 import os
@@ -206,11 +206,110 @@ def build():
     return kats
 
 
+def build3():
+    """K14..K19 (round 3): the branches K1..K13 do not reach. Derivations: kat_derivation.md, second part."""
+    kats = []
+
+    # ---- K14: 16-bit SCE, order 5 (unpcBlock5, predictor.go:198-310): early stops and full walks, both signs -------
+    bw = BitWriter()
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 1, 0, [2, -1, 1, 0, 1])
+    unary(bw, [7, 2, -3, 1, 2, -1, 4, -5, 20, -30, 2], 16)
+    bw.put(7, 3)
+    kats.append({"name": "K14 SCE order 5 (unpcBlock5)", "frame_length": 11, "bit_depth": 16, "num_channels": 1, "mb": 255,
+                 "packet": bw.hex(), "pcm": le([7, 9, 6, 7, 9, 8, 12, 5, 31, -3, 41], 2)})
+
+    # ---- K15: the mean clamp for n > 0xffff (golomb.go:216-218), then k = 7 codes; V with two zero-length runs -----
+    bw = BitWriter()
+    elem_header(bw, 1)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 0, 4, [])
+    chan_header(bw, 0, 0, 4, [])
+    bw.raw("111111111").put(0x10001, 17)   # U0: escape code, n = 65537 -> del = -32769; mean clamped to 0xffff
+    bw.raw("10 0000101")                    # U1: k = 7, m = 127: pre 1, v 5 -> n = 131 -> del = -66
+    bw.raw("0 000000")                      # U2: k = 7: pre 0, v < 2 -> n = 0, six bits behind the prefix
+    bw.raw("110 00 0 00 10")                # V: +1, run of 0, -1 (zmode), run of 0, +1 (zmode)
+    bw.put(7, 3)
+    kats.append({"name": "K15 mean clamp n > 0xffff, k = 7, zero-length runs", "frame_length": 3, "bit_depth": 16,
+                 "num_channels": 2, "mb": 10, "packet": bw.hex(), "pcm": "FF7F0100BEFFFFFF00000100"})
+
+    # ---- K16: 32-bit SCE without shift bytes: chanBits 32, getStreamBits' fifth byte (golomb.go:90-99) -------------
+    bw = BitWriter()
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 0, 0, [])
+    bw.raw("110")                            # s0: k = 1, n = 2 -> +1
+    bw.raw("111111111").put(0x89ABCDEE, 32)  # s1: escape code read at bit offset 19 of the stream: 32 + 3 > 32
+    bw.raw("0 0000010")                      # s2: the clamp left mean = 0xffff: k = 7, v = 2 -> n = 1 -> -1
+    bw.put(7, 3)
+    kats.append({"name": "K16 32-bit literal across five bytes", "frame_length": 3, "bit_depth": 32, "num_channels": 1,
+                 "mb": 255, "packet": bw.hex(), "pcm": "01000000F7E6D544FFFFFFFF"})
+
+    # ---- K17: zero run whose length is the 16-bit literal of dynGet (golomb.go:121-129) ----------------------------
+    bw = BitWriter()
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 0, 4, [])
+    bw.raw("0")                              # s0: n = 0; mean 10 -> zero run, k = 4
+    bw.raw("111111111").put(17, 16)          # run of 17 as a literal
+    bw.raw("110")                            # s18: zmode: n = 2 -> nd = 3 -> -2; mean 120 -> zero run, k = 3
+    bw.raw("0 00")                           # run of 0
+    bw.raw("0")                              # s19: zmode: nd = 1 -> -1
+    bw.put(7, 3)
+    kats.append({"name": "K17 zero run with a 16-bit literal length", "frame_length": 20, "bit_depth": 16,
+                 "num_channels": 1, "mb": 10, "packet": bw.hex(), "pcm": le([0] * 18 + [-2, -1], 2)})
+
+    # ---- K18: 8 channels: SCE CPE CPE CPE LFE -> L R C LFE Ls Rs Lc Rc (decoder.go:63) -----------------------------
+    bw = BitWriter()
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 0, 0, [])
+    unary(bw, [10, 11], 16)                                     # C
+    for u, v in (([20, 21], [30, 31]), ([40, 41], [50, 51]), ([60, 61], [-70, -71])):   # Lc Rc, L R, Ls Rs
+        elem_header(bw, 1)
+        bw.put(0, 8).put(0, 8)
+        chan_header(bw, 0, 0, 0, [])
+        chan_header(bw, 0, 0, 0, [])
+        unary(bw, u, 17)
+        unary(bw, v, 17)
+    elem_header(bw, 3)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 0, 0, [])
+    unary(bw, [-1, -2], 16)                                     # LFE
+    bw.put(7, 3)
+    frames = [40, 50, 10, -1, 60, -70, 20, 30, 41, 51, 11, -2, 61, -71, 21, 31]
+    kats.append({"name": "K18 8-channel layout", "frame_length": 2, "bit_depth": 16, "num_channels": 8, "mb": 255,
+                 "packet": bw.hex(), "pcm": le(frames, 2)})
+
+    # ---- K19: FIL of 0 bytes, DSE with the 255 + n count and alignment (decoder.go:555-574), then an SCE -----------
+    bw = BitWriter()
+    bw.put(6, 3).put(0, 4)                                      # FIL, count 0: the DSE starts at bit 7
+    bw.put(4, 3).put(5, 4).put(1, 1).put(255, 8).put(2, 8)      # DSE: align flag, count 255 + 2 = 257
+    bw.align()                                                  # bit 31 -> 32
+    for i in range(257):
+        bw.put((i * 7 + 1) & 0xFF, 8)
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 0, 0, [])
+    unary(bw, [3, -4], 16)
+    bw.put(7, 3)
+    kats.append({"name": "K19 DSE with extended count", "frame_length": 2, "bit_depth": 16, "num_channels": 1, "mb": 255,
+                 "packet": bw.hex(), "pcm": "0300FCFF"})
+    return kats
+
+
 def main():
+    here = os.path.dirname(os.path.abspath(__file__))
     out = {"_source": "hand-built packets; expected PCM derived on paper from the reference source in "
                       "tests/golden/kat_derivation.md (no decoder was run to produce it)",
            "config_common": {"pb": 40, "kb": 14, "max_run": 255}, "vectors": build()}
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat2.json")
+    path = os.path.join(here, "kat2.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path, len(out["vectors"]), "vectors")
+    out["vectors"] = build3()
+    path = os.path.join(here, "kat3.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path, len(out["vectors"]), "vectors")

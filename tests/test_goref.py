@@ -31,13 +31,14 @@ def test_goref_reproduces_the_hand_derived_kats():
         cfg = goref.PacketConfig(v["frame_length"], c["bit_depth"], v["num_channels"], c["pb"], c["mb"], c["kb"], c["max_run"])
         pcm, frames, st = goref.decode_packet(cfg, bytes.fromhex(v["packet"].replace(" ", "")))
         assert st == 0 and pcm.hex().upper() == v["pcm"].upper(), v["name"]
-    k = json.load(open(os.path.join(HERE, "golden", "kat2.json")))
-    c = k["config_common"]
-    for v in k["vectors"]:
-        cfg = goref.PacketConfig(v["frame_length"], v["bit_depth"], v["num_channels"], c["pb"], v["mb"], c["kb"], c["max_run"])
-        pcm, frames, st = goref.decode_packet(cfg, bytes.fromhex(v["packet"]))
-        assert st == 0 and frames == v.get("frames", v["frame_length"]), v["name"]
-        assert pcm.hex().upper() == v["pcm"].upper(), v["name"]
+    for name in ("kat2.json", "kat3.json"):
+        k = json.load(open(os.path.join(HERE, "golden", name)))
+        c = k["config_common"]
+        for v in k["vectors"]:
+            cfg = goref.PacketConfig(v["frame_length"], v["bit_depth"], v["num_channels"], c["pb"], v["mb"], c["kb"], c["max_run"])
+            pcm, frames, st = goref.decode_packet(cfg, bytes.fromhex(v["packet"]))
+            assert st == 0 and frames == v.get("frames", v["frame_length"]), v["name"]
+            assert pcm.hex().upper() == v["pcm"].upper(), v["name"]
 
 
 @pytest.mark.parametrize("fl,depth,ch,kb", [(64, 16, 2, 14), (48, 24, 2, 14), (40, 16, 1, 14), (32, 20, 2, 14),

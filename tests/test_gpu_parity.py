@@ -35,10 +35,10 @@ def test_known_answer_packets_on_gpu(pkg):
 
 
 def test_hand_derived_predictor_and_matrix_packets_on_gpu(pkg):
-    """K5..K13 (tests/golden/kat_derivation.md) through DecodePacket on the GPU."""
+    """K5..K13 and K14..K19 (tests/golden/kat_derivation.md) through DecodePacket on the GPU."""
     k = json.load(open(os.path.join(HERE, "golden", "kat2.json")))
     c = k["config_common"]
-    for v in k["vectors"]:
+    for v in k["vectors"] + json.load(open(os.path.join(HERE, "golden", "kat3.json")))["vectors"]:
         cfg = pkg.PacketConfig(FrameLength=v["frame_length"], BitDepth=v["bit_depth"], NumChannels=v["num_channels"],
                                PB=c["pb"], MB=v["mb"], KB=c["kb"], MaxRun=c["max_run"])
         with pkg.NewPacketDecoder(cfg) as dec:

@@ -51,13 +51,32 @@ def test_hand_derived_predictor_and_matrix_packets(oracle, vec):
     assert pcm.hex().upper() == vec["pcm"].upper()
 
 
+def _kat3():
+    return json.load(open(os.path.join(HERE, "golden", "kat3.json")))
+
+
+@pytest.mark.parametrize("vec", _kat3()["vectors"], ids=lambda v: v["name"].split()[0])
+def test_hand_derived_packets_of_round_3(oracle, vec):
+    """K14..K19 (tests/golden/kat_derivation.md, second part): unpcBlock5 (predictor.go:198-310), the mean clamp for
+    n > 0xffff (golomb.go:216-218), getStreamBits' fifth byte (golomb.go:90-99), dynGet's 16-bit literal
+    (golomb.go:121-129), the 8-channel layout (decoder.go:63) and DSE's extended count (decoder.go:560-563)."""
+    c = _kat3()["config_common"]
+    cfg = oracle.make_config(vec["frame_length"], vec["bit_depth"], vec["num_channels"], c["pb"], vec["mb"], c["kb"],
+                             c["max_run"])
+    st, frames, pcm = oracle.decode_packet(cfg, bytes.fromhex(vec["packet"]))
+    assert st == 0
+    assert frames == vec["frame_length"]
+    assert pcm.hex().upper() == vec["pcm"].upper()
+
+
 def test_kat2_json_is_what_kat_build_packs():
-    """kat2.json is the output of tests/golden/kat_build.py (a bit packer + typed-in expectations), nothing else."""
+    """kat2.json / kat3.json are the output of tests/golden/kat_build.py (a bit packer + typed-in expectations), nothing else."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("kat_build", os.path.join(HERE, "golden", "kat_build.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.build() == _kat2()["vectors"]
+    assert m.build3() == _kat3()["vectors"]
 
 
 def test_golden_packets(oracle):
