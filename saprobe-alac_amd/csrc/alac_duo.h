@@ -45,7 +45,7 @@ namespace alac {
 #endif
 constexpr uint32_t DUO_CHUNK = ALAC_DUO_CHUNK;
  /* steps per queue buffer (a multiple of 8) */
-enum { ROLE_A = 0, ROLE_B = 1, ROLE_BOTH = 2 };
+enum { ROLE_A = 0, ROLE_B = 1, ROLE_BOTH = 2, ROLE_C = 3 };
 
 /*
  * One channel of a regular element. s: the lane's Golomb + reader state (role A). NA: this channel's predictor
@@ -55,11 +55,11 @@ enum { ROLE_A = 0, ROLE_B = 1, ROLE_BOTH = 2 };
  * mode (per lane) != 0: the delta pre-pass of decoder.go:307-309 runs on the residual stream first (split
  * pipeline only: regular packets have mode 0).
  */
-template <class W, class B, int NA, int OUT, int ROLE, bool F16, bool NARROW, bool EA, bool UN8W = false>
+template <class W, class B, int NA, int OUT, int ROLE, bool F16, bool NARROW, bool EA, bool UN8W = false, bool EC = false>
 ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
                         uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
                         uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb, uint32_t mode) {
-    constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
+    constexpr bool DO_A = ROLE == ROLE_A || ROLE == ROLE_BOTH, DO_B = ROLE == ROLE_B || ROLE == ROLE_BOTH;
     constexpr bool RAW = OUT == OUT_RAW;
     constexpr bool LAST = OUT == OUT_STEREO || OUT == OUT_MONO || RAW; /* B stages what it reconstructs */
     constexpr bool CPE = OUT == OUT_STEREO;
@@ -73,8 +73,14 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     constexpr uint32_t BIAS = 0x80000000u;
     /* EA: the PCM writer runs in wave A (long predictors: B is the longer of the two). Samples then go B -> A
      * through the second half of each queue buffer, in chunks of half the size, and A writes them two chunks late. */
-    constexpr bool EMIT_A = EA && LAST && !RAW;
-    constexpr bool DO_EMIT = EMIT_A ? DO_A : DO_B;
+    /* EC (round 3): a THIRD wave writes the PCM (role C: unmix, packing, stager, flush; it reads the U tile itself).
+     * What a pair's step takes is the issue time of its longest wave, and since the entropy step lost a third of its
+     * instructions that is the predictor wave in the last phase (predictor + writer: 90 issue slots against 66 in the
+     * U phase): with the writer in a wave of its own all three stay near 66. Same queue protocol as EA. */
+    static_assert(!(EA && EC), "one writer");
+    constexpr bool DO_C = (ROLE == ROLE_C || ROLE == ROLE_BOTH) && EC;
+    constexpr bool EMIT_A = (EA || EC) && LAST && !RAW; /* the samples leave wave B through the queue */
+    constexpr bool DO_EMIT = EMIT_A ? (EC ? DO_C : DO_A) : DO_B;
     constexpr uint32_t CH = EMIT_A ? DUO_CHUNK / 2u : DUO_CHUNK;
     const uint32_t na = GEN ? na_rt : (uint32_t)NA;
     uint32_t kb = cfg.kb;
@@ -221,10 +227,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
         for (int t = NR; t >= 1; --t) hb[t] = hb[t - 1];
         hb[0] = (uint32_t)o ^ BIAS;
         if (!LAST) *wv.u_row(i) = o; /* dead lanes write their own unused cell */
-        else if (EMIT_A) {
-            wv.rq_write(buf, CH + j, o);
-            if (CPE) wv.rq_write(buf, 2u * CH + j, u); /* the U sample rides along: wave A has no business with the tile */
-        }
+        else if (EMIT_A) wv.rq_write(buf, CH + j, o);
         else emit(i, o, u, sw, jj, fp);
     };
     /* A (EMIT_A): inputs of the chunk it writes, requested before the Golomb work of the iteration */
@@ -241,7 +244,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             sw_v[j] = 0;
             if (i < n_it) { /* scalar: rows past n_it do not exist in the tile */
                 sq_v[j] = wv.rq_read(buf, CH + j);
-                if (CPE) u_v[j] = wv.rq_read(buf, 2u * CH + j);
+                if (CPE) u_v[j] = *wv.u_row(i);
                 if (merge_any) sw_v[j] = bits.window_raw(shift_pos + i * sstep_a);
             }
         }
@@ -343,7 +346,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
                         dv[j] = RMEM ? dpre[j] : wv.rq_read(buf, g + j);
                         uv[j] = AHEAD ? upre[j] : 0;
                         sv[j] = AHEAD ? spre[j] : 0ull;
-                        if ((HBM_IN || EMIT_A) && !AHEAD && CPE) uv[j] = *wv.u_row(row0 + j);
+                        if (HBM_IN && !AHEAD && CPE) uv[j] = *wv.u_row(row0 + j);
                     }
                     uint32_t gq[NSUB][3];
 #pragma unroll
@@ -461,7 +464,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             if (i == 0 || (GEN && na == 0)) o = del;
             else if (i <= na || (GEN && na == 31)) o = sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
             else o = predict(del, wrap_yes{});
-            put(buf, j, i, o, CPE ? *wv.u_row(i) : 0,
+            put(buf, j, i, o, (CPE && !EMIT_A) ? *wv.u_row(i) : 0,
                 (!EMIT_A && merge_any) ? bits.window_raw(shift_pos + i * sstep) : 0ull, 0u, fp_no{});
             if (LAST && !EMIT_A) wv.st_step();
             if (FP_OK && i + 1u == ns) (void)wv.st_finish(); /* see run_groups */
@@ -478,7 +481,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     for (uint32_t c = 0; c < iters; ++c) {
         ALAC_DUO_STAMP(0);
         if (DO_A) {
-            if (EMIT_A && c >= 2u) fetch_chunk(c - 2u);
+            if (EMIT_A && !EC && c >= 2u) fetch_chunk(c - 2u);
             if (c < nch) golomb_chunk(c);
         }
         ALAC_DUO_STAMP(1);
@@ -486,8 +489,14 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             if (c >= 1u && c <= nch) predict_chunk(c - 1u);
         }
         ALAC_DUO_STAMP(2);
-        if (DO_A && EMIT_A) {
+        if (DO_A && EMIT_A && !EC) {
             if (c >= 2u) emit_chunk(c - 2u);
+        }
+        if (DO_C && EMIT_A) {
+            if (c >= 2u) {
+                fetch_chunk(c - 2u);
+                emit_chunk(c - 2u);
+            }
         }
         ALAC_DUO_STAMP(3);
         wv.duo_sync();
@@ -501,35 +510,31 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
  * does not; for single channels the writer balances the pair better in A from order 5 on (mono 16-bit: 1.93 ->
  * 1.63 ms). Not for pairs: the writer then needs the U tile and the shift bytes from HBM, and in wave A every wait
  * for the bitstream ring (vmcnt counts in order) would also wait for those loads (measured: 3.15 -> 3.55 ms). */
-/* Round 3: the entropy step lost a third of its instructions (gol_step), so the writer of 16-bit pairs moved over too:
- * the predictor wave hands wave A the V sample AND the U sample it has loaded from the tile, both through the LDS queue,
- * so wave A still waits on nothing but its bitstream ring. */
-#ifndef ALAC_EA_CPE_MIN
-#define ALAC_EA_CPE_MIN 99
-#endif
-ALAC_DEV constexpr bool duo_emit_in_a(uint32_t na, bool cpe, bool f16) {
-    return cpe ? (f16 && na >= (uint32_t)ALAC_EA_CPE_MIN && na <= 16u) : (na >= 5u && na <= 16u);
-}
+ALAC_DEV constexpr bool duo_emit_in_a(uint32_t na, bool cpe) { return !cpe && na >= 5u && na <= 16u; }
 
 /* the order switch is scalar: NA is wave-uniform by construction of the waves. Role A never looks at the order. */
-template <class W, int OUT, int ROLE, bool F16, bool NARROW = true, bool UN8W = false, class B>
+template <class W, int OUT, int ROLE, bool F16, bool NARROW = true, bool UN8W = false, bool EC = false, class B>
 ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits, RegLane<W>& s, uint32_t size,
                            uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
                            int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb, uint32_t mode = 0u) {
 #define ALAC_DUO_CASE(N)                                                                                              \
     case N:                                                                                                           \
-        duo_phase<W, B, N, OUT, ROLE, F16, NARROW, CAN_EA && duo_emit_in_a(N, OUT == OUT_STEREO, F16), UN8W>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, \
+        duo_phase<W, B, N, OUT, ROLE, F16, NARROW, CAN_EA && duo_emit_in_a(N, OUT == OUT_STEREO), UN8W, EC>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, \
                                                                        den_shift, chan_bits, mix_res, mix_sh, na,     \
                                                                        shift_pos, sb, mode);                          \
         break;
-    constexpr bool CAN_EA = NARROW && (OUT == OUT_STEREO || OUT == OUT_MONO); /* phases that write PCM; not the wide ones */
-    if (ROLE == ROLE_A) {
-        if (CAN_EA && duo_emit_in_a(na, OUT == OUT_STEREO, F16))
-            duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, true>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
-                                                          mix_res, mix_sh, na, shift_pos, sb, mode);
-        else
-            duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, false>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
-                                                           mix_res, mix_sh, na, shift_pos, sb, mode);
+    /* phases that write PCM; not the wide ones; not when a third wave writes */
+    constexpr bool CAN_EA = !EC && NARROW && (OUT == OUT_STEREO || OUT == OUT_MONO);
+    if (ROLE == ROLE_A || ROLE == ROLE_C) { /* neither looks at the order */
+        if constexpr (CAN_EA) {
+            if (duo_emit_in_a(na, OUT == OUT_STEREO)) {
+                duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, true, false, false>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift,
+                                                                            chan_bits, mix_res, mix_sh, na, shift_pos, sb, mode);
+                return;
+            }
+        }
+        duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, false, false, EC>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
+                                                                  mix_res, mix_sh, na, shift_pos, sb, mode);
         return;
     }
     switch (na) {
@@ -550,8 +555,8 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits,
         ALAC_DUO_CASE(15)
         ALAC_DUO_CASE(16)
         default:
-            duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, false>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
-                                                           mix_res, mix_sh, na, shift_pos, sb, mode);
+            duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, false, false, EC>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
+                                                                      mix_res, mix_sh, na, shift_pos, sb, mode);
             break;
     }
 #undef ALAC_DUO_CASE
@@ -563,10 +568,13 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits,
  * returns the status word and sets *frames_out. The caller playing role B passes the same arguments; its return
  * value and *frames_out mean nothing.
  */
-template <class W, int ROLE, int WIDE_SEL = -1, int DEPTH_SEL = 0>
+/* EC: the caller's workgroup has a third wave (ROLE_C) that writes the PCM of the narrow phases (duo_phase); its return
+ * value and *frames_out mean nothing either. */
+template <class W, int ROLE, int WIDE_SEL = -1, int DEPTH_SEL = 0, bool EC = false>
 ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
                                     uint32_t avail, uint8_t* out, uint32_t* frames_out) {
-    constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
+    constexpr bool DO_A = ROLE == ROLE_A || ROLE == ROLE_BOTH, DO_B = ROLE == ROLE_B || ROLE == ROLE_BOTH;
+    constexpr bool DO_C = ROLE == ROLE_C || ROLE == ROLE_BOTH;
     const BitsT<false> bits{pkt, size, avail}; /* regular packets hold at least 12 bytes (classify_regular) */
     const bool cpe = cfg.num_channels == 2;
     /* chanBits > 23: predict_wide. WIDE_SEL 0 / 1: the caller only ever passes keys of that kind (the other half is
@@ -605,8 +613,8 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     const uint32_t sb = (cfg.bit_depth == 24 || cfg.bit_depth == 32) ? bs * 8u : 0u;
     const uint32_t n_it = wv.max_u32(ns);
     /* the stager belongs to the wave that writes the PCM of the last channel (duo_emit_in_a) */
-    const bool emit_a = !wide && duo_emit_in_a(cpe ? na_v : na_u, cpe, cfg.bit_depth == 16);
-    const bool writer = emit_a ? DO_A : DO_B;
+    const bool emit_a = !EC && !wide && duo_emit_in_a(cpe ? na_v : na_u, cpe);
+    const bool writer = (EC && !wide) ? DO_C : (emit_a ? DO_A : DO_B);
     if (writer && live) wv.st_begin(out);
 
     /* ---- U (or the mono channel) ---- */
@@ -616,8 +624,8 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     s.pb = (cfg.pb * ((hu >> 5) & 7u)) / 4u; /* decoder.go:299 */
     if (DO_A) s.rd.start(wv, live ? s.pos : s.rd.bias);
     if constexpr (WIDE_SEL != 1) if (!wide) {
-        if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
-        else duo_phase_na<W, OUT_MONO, ROLE, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
+        if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false, true, false, EC>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
+        else duo_phase_na<W, OUT_MONO, ROLE, false, true, false, EC>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
     }
     if constexpr (WIDE_SEL != 0) if (wide) {
         if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
@@ -639,9 +647,9 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
         /* DEPTH_SEL 16 / 24 / 32: the caller's configuration has that sample width (24 stands for both 3-byte depths) */
         if constexpr (WIDE_SEL != 1) if (!wide) {
             if constexpr (DEPTH_SEL == 0 || DEPTH_SEL == 16) if (cfg.bit_depth == 16)
-                duo_phase_na<W, OUT_STEREO, ROLE, true>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+                duo_phase_na<W, OUT_STEREO, ROLE, true, true, false, EC>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
             if constexpr (DEPTH_SEL != 16) if (cfg.bit_depth != 16)
-                duo_phase_na<W, OUT_STEREO, ROLE, false, true, DEPTH_SEL == 24>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+                duo_phase_na<W, OUT_STEREO, ROLE, false, true, DEPTH_SEL == 24, EC>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
         }
         if (err_u == 0 && s.err != 0) err_chan = 1;
     }

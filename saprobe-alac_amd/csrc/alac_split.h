@@ -41,7 +41,7 @@ constexpr uint32_t TASK_NONE = 0xffffu;
 template <class W, int ROLE>
 ALAC_DEV void decode_channel_task(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
                                   uint32_t avail, const ChanDesc& d, int32_t* row) {
-    constexpr bool DO_A = ROLE != ROLE_B, DO_B = ROLE != ROLE_A;
+    constexpr bool DO_A = ROLE == ROLE_A || ROLE == ROLE_BOTH, DO_B = ROLE == ROLE_B || ROLE == ROLE_BOTH;
     const Bits bits{pkt, size, avail};
     const uint32_t na = key & 31u;
     const bool narrow = (key & 32u) == 0;

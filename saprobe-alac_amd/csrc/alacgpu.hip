@@ -360,10 +360,13 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
                    d_frames, d_status, (int32_t*)dec->scratch_u.p, (const uint32_t*)dec->cu_number.p,
                    (uint32_t*)((uint8_t*)plan + plan_claims_offset()), ppw, dec->n_cu, 0u};
         const uint32_t slots = (uint32_t)max_waves(dec, n, ppw);
-        auto pairs = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(slots), dim3(2 * kWave), 0, dec->stream, a); };
+        auto pairs = [&](auto kernel, uint32_t roles = 2u) { hipLaunchKernelGGL(kernel, dim3(slots), dim3(roles * kWave), 0, dec->stream, a); };
         switch (dec->cfg.bit_depth) {
             case 16:
                 a.cap = pair_capacity(alac_decode_16g);
+                /* one round or less: workgroups of entropy, predictor and writer waves (k_dec16t.hip); more: wave pairs */
+                /* (slots is an upper bound: a partly filled wave per key present; the kernels decide on the real count) */
+                if ((size_t)slots <= (size_t)4 * dec->n_cu + 18 * 18 + 8) pairs(alac_decode_16t, 3u);
                 pairs(alac_decode_16);
                 /* as many workgroups as the device holds at once: they share the slots out among themselves */
                 if ((size_t)slots > (size_t)4 * dec->n_cu && a.cap > 4u)

@@ -68,7 +68,7 @@ struct HostWave {
     }
     uint32_t ring_read(uint32_t slot) const { return ring[slot]; }
     /* residual queue of alac_duo.h: one lane, both roles played by the same caller, so the barriers are no-ops */
-    int32_t rq[2][alac::DUO_CHUNK + alac::DUO_CHUNK / 2] = {{0}};
+    int32_t rq[2][alac::DUO_CHUNK] = {{0}};
     void rq_write(uint32_t buf, uint32_t j, int32_t v) { rq[buf][j] = v; }
     int32_t rq_read(uint32_t buf, uint32_t j) const { return rq[buf][j]; }
     void duo_sync() {}
@@ -150,7 +150,7 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
                 if (classes_out) classes_out[i] = key;
                 /* the same instantiations as the GPU library's kernels, one per sample width (k_dec16 / 24 / 32.hip) */
                 if (dc.bit_depth == 16)
-                    status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH, -1, 16>(wv, dc, key, true, p, sizes[i], avail, o, &frames_out[i]);
+                    status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH, -1, 16, true>(wv, dc, key, true, p, sizes[i], avail, o, &frames_out[i]);
                 else if (dc.bit_depth == 32)
                     status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH, -1, 32>(wv, dc, key, true, p, sizes[i], avail, o, &frames_out[i]);
                 else
