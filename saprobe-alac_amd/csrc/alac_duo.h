@@ -63,9 +63,10 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     constexpr bool RAW = OUT == OUT_RAW;
     constexpr bool LAST = OUT == OUT_STEREO || OUT == OUT_MONO || RAW; /* B stages what it reconstructs */
     constexpr bool CPE = OUT == OUT_STEREO;
-    /* what role B reads: residuals through the LDS queue (the entropy wave has slack: it folds the sign, golomb.go:206-209),
-     * n + zmode as the scan left it in the rows of the split pipeline (a lone chain: every instruction counts there) */
-    constexpr bool QND = W::kResMem;
+    /* what role B reads: residuals through the LDS queue where the entropy wave has slack (it folds the sign,
+     * golomb.go:206-209); n + zmode where it has not: as the scan left it in the rows of the split pipeline (a lone chain:
+     * every instruction counts there), and in workgroups with a writer wave, where the entropy wave sets the pace */
+    constexpr bool QND = W::kResMem || EC; /* (EC is declared with the template: with a writer wave the entropy wave is the longest) */
     constexpr bool GEN = NA == 0;
     /* GEN only ever serves orders 0 (copy) and 31 (delta): every order with taps has its own instantiation */
     constexpr int NR = GEN ? 1 : NA;
@@ -136,6 +137,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     /* A: residuals of chunk c (DynDecomp, golomb.go:167-247). Whole chunks run as straight-line groups of four steps (the bitstream ring is topped
      * up once per group, 4 steps ahead of need). */
     uint32_t ns_live = s.err == 0 ? ns : 0u;
+    auto qval = [&](uint32_t nd) -> int32_t { return QND ? (int32_t)nd : gol_unfold(nd); };
     auto golomb_chunk = [&](uint32_t c) {
         const uint32_t buf = c & 1u;
         if ((c + 1u) * CH <= n_it) {
@@ -145,7 +147,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
                 s.near = gol_near(s, c * CH + g, ns_live);
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; ++j)
-                    wv.rq_write(buf, g + j, gol_unfold(gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, c * CH + g + j, ns, ns_live)));
+                    wv.rq_write(buf, g + j, qval(gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, c * CH + g + j, ns, ns_live)));
             }
             return;
         }
@@ -157,7 +159,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
                 s.rd.tick(wv);
                 s.near = gol_near(s, i, ns_live);
             }
-            wv.rq_write(buf, j, gol_unfold(gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i, ns, ns_live)));
+            wv.rq_write(buf, j, qval(gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i, ns, ns_live)));
         }
     };
     /* PCM of frame i from its last channel's sample o (unmix / shift merge / packing / stager).
@@ -240,12 +242,32 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
         for (uint32_t j = 0; j < CH; ++j) {
             const uint32_t i = c * CH + j;
             sq_v[j] = 0;
-            u_v[j] = 0;
-            sw_v[j] = 0;
+            if (!EC) {
+                u_v[j] = 0;
+                sw_v[j] = 0;
+            }
             if (i < n_it) { /* scalar: rows past n_it do not exist in the tile */
                 sq_v[j] = wv.rq_read(buf, CH + j);
-                if (CPE) u_v[j] = *wv.u_row(i);
-                if (merge_any) sw_v[j] = bits.window_raw(shift_pos + i * sstep_a);
+                if (!EC) {
+                    if (CPE) u_v[j] = *wv.u_row(i);
+                    if (merge_any) sw_v[j] = bits.window_raw(shift_pos + i * sstep_a);
+                }
+            }
+        }
+    };
+    /* the writer wave: what a chunk needs from memory (U samples, shift values) does not come from wave B, so it is
+     * asked for a whole iteration ahead */
+    int32_t u_n[CH];
+    uint64_t sw_n[CH];
+    auto fetch_mem_ahead = [&](uint32_t c) {
+#pragma unroll
+        for (uint32_t j = 0; j < CH; ++j) {
+            const uint32_t i = c * CH + j;
+            u_n[j] = 0;
+            sw_n[j] = 0;
+            if (i < n_it) {
+                if (CPE) u_n[j] = *wv.u_row(i);
+                if (merge_any) sw_n[j] = bits.window_raw(shift_pos + i * sstep_a);
             }
         }
     };
@@ -493,6 +515,14 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             if (c >= 2u) emit_chunk(c - 2u);
         }
         if (DO_C && EMIT_A) {
+            if (c >= 2u) {
+#pragma unroll
+                for (uint32_t j = 0; j < CH; ++j) {
+                    u_v[j] = u_n[j];
+                    sw_v[j] = sw_n[j];
+                }
+            }
+            if (c >= 1u && c <= nch) fetch_mem_ahead(c - 1u);
             if (c >= 2u) {
                 fetch_chunk(c - 2u);
                 emit_chunk(c - 2u);

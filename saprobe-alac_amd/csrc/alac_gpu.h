@@ -176,7 +176,7 @@ struct Plan {
     uint32_t balance[2][512]; /* per SIMD of the CU, a byte each: entropy waves - predictor waves placed there */
     uint32_t queue[2];
 #ifdef ALAC_DUO_PROF
-    unsigned long long prof[32]; /* [role A: U phase 0..3, last phase 4..7 | role B: 16..19, 20..23] */
+    unsigned long long prof[32]; /* [role A: U phase 0..3, last phase 4..7 | role C: 8..15 | role B: 16..19, 20..23] */
 #endif
 };
 

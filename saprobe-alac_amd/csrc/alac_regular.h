@@ -432,9 +432,8 @@ ALAC_DEV uint32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, u
      * independent instruction at hand. The step is three chains — P: position -> window -> prefix -> value -> position;
      * M: mean -> k, and mean * pb; Z: the zero-run countdown — and the statements below alternate between them so that
      * (almost) nothing uses the result of its predecessor. The slide of the window cache is done here too, before the
-     * rare cases are known: the slow path reseeks anyway. ESC: escape codes take a few instructions of their own
-     * behind a wave-uniform branch (entropy wave of a pair: it has issue slots to spare); without it they are one more
-     * rare case (the scan: a lone chain, where two instructions more in every step cost more than the rare detour). */
+     * rare cases are known: the slow path reseeks anyway. ESC: inside the rare branch an escape code that is nothing
+     * but that takes a few instructions instead of golomb_slow. */
     const uint32_t o_pos = s.pos, o_mean = s.mean, o_zrem = s.zrem;
     RingRd<W>& rd = s.rd;
 #ifdef ALAC_PAD_A /* experiment: what an instruction more in the entropy step costs */
@@ -466,33 +465,17 @@ ALAC_DEV uint32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, u
     const uint32_t c2 = umin(vm1, 1u);
     const uint32_t mt = o_mean - t9;                                                    /* M */
     uint32_t n = pk + vm1 - pre;             /* pre * (2^k - 1) + ... */
-    uint32_t cons = pre + k + c2;            /* prefix + 1, then k bits (v >= 2) or k - 1 */
-    uint32_t esc_flag = 0;
-    if (ESC) {
-        /* Nine ones: an escape code, the value is the chan_bits bits behind them (golomb.go:184-186). One sample in two
-         * thousand of music has one, which is one step in thirty of a wave of 64: for chan_bits <= 23 the whole code
-         * lies in the window already (a lane within reach of the packet's end takes the slow path anyway: near). Wider
-         * values are left to golomb_slow: an n that trips the n > 0xffff flag sends the lane there. */
-        const uint32_t esc = ALAC_SUBSAT(pre, 8u) & norun;
-        if (ALAC_UNLIKELY(wv.any(esc != 0u))) {
-            if (esc != 0u) {
-                const bool inl = chan_bits <= 23u;
-                n = inl ? ALAC_BFE(w, 23u - chan_bits, chan_bits) : 0xffffffffu;
-                cons = 9u + chan_bits;
-            }
-        }
-    } else {
-        esc_flag = ALAC_SUBSAT(pre, 8u);
-    }
+    const uint32_t cons = pre + k + c2;      /* prefix + 1, then k bits (v >= 2) or k - 1 */
+    const uint32_t esc = ALAC_SUBSAT(pre, 8u); /* nine ones: an escape code (golomb.go:184) */
     n &= norun;
     const uint32_t cm = cons & norun;
     const uint32_t mean2 = ALAC_MULU24(s.pb, n) + mt; /* golomb.go:215; n <= 0xffff or rare */
     const uint32_t pos2 = o_pos + cm;
-    const uint32_t nhi = (n >> 16) | esc_flag;
+    const uint32_t nhi = (n >> 16) | esc;
     const uint32_t ni = pos2 >> 5;
     const uint32_t zs = ALAC_SUBSAT(128u, mean2);
     const uint32_t cmk = rd.widx - ni; /* 0, or all ones when the position has entered the next dword */
-    /* rare cases, as nonzero-means-true flags: (escape code, golomb.go:184,) n > 0xffff (:216), near (RegLane), start of
+    /* rare cases, as nonzero-means-true flags: escape code (golomb.go:184), n > 0xffff (:216), near (RegLane), start of
      * a zero run (:223: mean * 4 < 512; mean2 < 2^26, the shift cannot wrap) */
     const uint32_t fl = nhi | s.near | zs;
     const uint32_t nw0 = ALAC_BFI(cmk, rd.w1, rd.w0);
@@ -506,14 +489,33 @@ ALAC_DEV uint32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, u
     rd.widx = ni;
     rd.w2 = wv.ring_read((ni + 2u) & (RingRd<W>::RING - 1u));
     uint32_t ndq = n;
-    /* a wave-uniform branch around the divergent one: the plain path then holds one compare and one scalar branch, and
-     * whatever the compiler needs to merge the two lanes' worth of state (copies, saved exec masks) stays in there */
+    /* ONE wave-uniform branch around everything rare, and the divergent ones inside it: the plain path holds one compare
+     * and one scalar branch, and whatever the compiler needs to merge the lanes' state (copies, saved exec masks) stays
+     * in there */
     if (ALAC_UNLIKELY(wv.any(rare != 0u))) {
         if (rare != 0u) {
-            s.pos = o_pos;
-            s.mean = o_mean;
-            s.zrem = o_zrem;
-            ndq = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns, ns_live);
+            /* ESC: an escape code and nothing else (one sample in two thousand of music has one, i.e. one step in thirty
+             * of a wave of 64): for chan_bits <= 23 the whole code lies in the window already, the value is the
+             * chan_bits bits behind the nine ones (golomb.go:184-186); the lane is not within reach of the packet's end
+             * (near), so nothing of getStreamBits' bounds can fail. Everything else, and an escape that turns out
+             * to be more than that (n > 0xffff, a zero run behind it), takes golomb_slow from the lane's old state. */
+            bool done = false;
+            if (ESC && esc != 0u && s.near == 0u && chan_bits <= 23u) {
+                const uint32_t n2 = ALAC_BFE(w, 23u - chan_bits, chan_bits);
+                const uint32_t m2 = ALAC_MULU24(s.pb, n2) + mt;
+                if (n2 <= 0xffffu && m2 >= 128u) {
+                    s.pos = o_pos + 9u + chan_bits;
+                    s.mean = m2;
+                    ndq = n2;
+                    done = true;
+                }
+            }
+            if (!done) {
+                s.pos = o_pos;
+                s.mean = o_mean;
+                s.zrem = o_zrem;
+                ndq = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns, ns_live);
+            }
             rd.reseek(wv, s.pos); /* the window cache afresh */
         }
     }
@@ -697,10 +699,10 @@ ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_
         s.rd.tick(wv);
         s.near = gol_near(s, i, ns_live);
         if (keep && go && i != 0u) ALAC_STORE4(res_row + (i - 4u), (int32_t)h0, (int32_t)h1, (int32_t)h2, (int32_t)h3);
-        h0 = gol_step<false>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i, my_ns, ns_live);
-        h1 = gol_step<false>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i + 1u, my_ns, ns_live);
-        h2 = gol_step<false>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i + 2u, my_ns, ns_live);
-        h3 = gol_step<false>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i + 3u, my_ns, ns_live);
+        h0 = gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i, my_ns, ns_live);
+        h1 = gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i + 1u, my_ns, ns_live);
+        h2 = gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i + 2u, my_ns, ns_live);
+        h3 = gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i + 3u, my_ns, ns_live);
     }
     if (keep && go && i != 0u) ALAC_STORE4(res_row + (i - 4u), (int32_t)h0, (int32_t)h1, (int32_t)h2, (int32_t)h3);
     for (; i < n_it; ++i) {
@@ -708,7 +710,7 @@ ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_
             s.rd.tick(wv);
             s.near = gol_near(s, i, ns_live);
         }
-        const uint32_t d = gol_step<false>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i, my_ns, ns_live);
+        const uint32_t d = gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i, my_ns, ns_live);
         if (keep && go) res_row[i] = (int32_t)d;
     }
     if (go) {

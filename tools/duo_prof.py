@@ -29,9 +29,9 @@ def step():
 step(); step(); step()
 L.alacgpu_debug_prof(buf)
 v = list(buf)
-names = ["A:fetch+golomb", "B:predict", "A:emit", "barrier wait"]
+names = ["A:fetch+golomb", "B:predict", "A/C:emit", "barrier wait"]
 waves = (P + 63) // 64
-for role, off in (("A", 0), ("B", 16)):
+for role, off in (("A", 0), ("B", 16), ("C", 8)):
     for phase, po in (("U phase", 0), ("last phase", 4)):
         tot = sum(v[off + po:off + po + 4])
         print("role %s, %s (ticks of s_memtime per wave, %d waves; %.1f per step of 4096):" % (role, phase, waves, tot / waves / 4096))
