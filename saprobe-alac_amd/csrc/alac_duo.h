@@ -140,14 +140,17 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     auto qval = [&](uint32_t nd) -> int32_t { return QND ? (int32_t)nd : gol_unfold(nd); };
     auto golomb_chunk = [&](uint32_t c) {
         const uint32_t buf = c & 1u;
-        if ((c + 1u) * CH <= n_it) {
+        if ((c + 1u) * CH <= n_it) { /* CH is 8 or 16: whole top-up periods */
 #pragma nounroll
-            for (uint32_t g = 0; g < CH; g += 4u) {
+            for (uint32_t g = 0; g < CH; g += GOL_TICK) {
                 s.rd.tick(wv);
                 s.near = gol_near(s, c * CH + g, ns_live);
+#pragma nounroll
+                for (uint32_t h = g; h < g + GOL_TICK; h += 4u) {
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j)
-                    wv.rq_write(buf, g + j, qval(gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, c * CH + g + j, ns, ns_live)));
+                    for (uint32_t j = 0; j < 4u; ++j)
+                        wv.rq_write(buf, h + j, qval(gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, c * CH + h + j, ns, ns_live)));
+                }
             }
             return;
         }
@@ -155,7 +158,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
         for (uint32_t j = 0; j < CH; ++j) {
             const uint32_t i = c * CH + j;
             if (i >= n_it) break;
-            if ((i & 3u) == 0) {
+            if ((i & (GOL_TICK - 1u)) == 0) {
                 s.rd.tick(wv);
                 s.near = gol_near(s, i, ns_live);
             }

@@ -183,11 +183,14 @@ ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32
 
 /* ---- the lean path's bit reader: an LDS ring per lane, refilled ahead of time --------------------------------
  * w0,w1 hold stream dwords widx, widx+1 and w2 the next one, as in FastRd, but they are fed from a ring of
- * W::kRingDw (16 or 32) dwords in LDS (W::ring_*), never straight from HBM. The ring is topped up 16 bytes at a time on a wave-uniform
- * schedule (every 4th step): tick() first commits the block whose global load was issued 4 steps earlier, then
- * issues the next one. So no step ever waits on an HBM/L2 round trip: the data a step needs left memory at
- * least four steps ago, and each packet byte is fetched from L2 exactly once. A plain step consumes <= 32 bits,
- * so 4 dwords per 4 steps sustain it (reseek() covers the slow path); start() prefills 16 dwords.
+ * W::kRingDw (32) dwords in LDS (W::ring_*), never straight from HBM. The ring is topped up 32 bytes at a time on a
+ * wave-uniform schedule (every 8th step): tick() first commits the block whose two global loads were issued 8 steps
+ * earlier, then issues the next ones, and each packet byte is fetched from L2 exactly once. EIGHT steps, not four
+ * (round 3): a lane enters a new 128-byte line every fourth block, so of a wave's 64 lanes some miss L2 at every
+ * top-up, and four steps of the entropy wave are shorter than a trip to HBM: with 16-byte blocks every 4 steps the
+ * wait at the top-up made the entropy step a quarter of the memory latency, whatever its instructions were (which is
+ * why taking a third of them out changed nothing at first). A plain step consumes <= 26 bits (<= 32 with an escape
+ * code), so 8 dwords per 8 steps sustain it (reseek() covers the slow path); start() prefills 24 dwords.
  * Positions handed to the reader are BIASED: stream bit p is position p + bias, bit p + bias of the dword array that
  * starts at `base` (the packet's start rounded down to a dword), so that no step adds the bias again.
  * Dense blob (see Bits): blocks that lie wholly inside the packet are loaded as they are (one global_load_dwordx4);
@@ -201,9 +204,10 @@ struct RingRd {
     uint32_t end_b;       /* first byte, counted from base, that is not packet data */
     uint32_t full;        /* dwords [0, full) of base lie wholly inside the packet */
     uint32_t w0, w1, w2, widx;
-    uint32_t fill;        /* ring holds dwords [fill - RING, fill); multiple of 4 */
+    uint32_t fill;        /* ring holds dwords [fill - RING, fill); multiple of 8 */
     static constexpr uint32_t RING = W::kRingDw;
-    uint32_t p0, p1, p2, p3;
+    static_assert(RING >= 32, "blocks of 8 dwords need a ring of 32");
+    uint32_t p0, p1, p2, p3, p4, p5, p6, p7;
     bool pend;
 
     ALAC_DEV void init(const uint8_t* pkt, uint32_t size) {
@@ -214,7 +218,7 @@ struct RingRd {
         end_b = size ? mis + size : 0u; /* a lane without a packet keeps nothing of what it reads */
         full = end_b >> 2;
         w0 = w1 = w2 = widx = fill = 0;
-        p0 = p1 = p2 = p3 = 0;
+        p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = 0;
         pend = false;
     }
     /* dword idx of a block that reaches past the packet, branch-free: fetch it (or, behind the packet, the last dword
@@ -226,32 +230,39 @@ struct RingRd {
         const uint32_t nb = end_b > lo ? umin(end_b - lo, 4u) : 0u;
         return v & (nb >= 4u ? 0xffffffffu : ((1u << (8u * nb)) - 1u));
     }
-    ALAC_DEV void load4(uint32_t at) {
-        /* one 16-byte load, 4-byte aligned. The dwords stay RAW (little-endian) in p0..p3: touching them here
-         * would make the wave wait for the load on the spot; commit() swaps them four steps later. */
-        if (at + 4u <= full) {
+    ALAC_DEV void load8(uint32_t at) {
+        /* two 16-byte loads, 4-byte aligned. The dwords stay RAW (little-endian) in p0..p7: touching them here
+         * would make the wave wait for the loads on the spot; commit() swaps them eight steps later. */
+        if (at + 8u <= full) {
             ALAC_LOAD4(base + at, p0, p1, p2, p3);
+            ALAC_LOAD4(base + at + 4u, p4, p5, p6, p7);
         } else { /* the last blocks of the packet, and everything behind it */
             p0 = tail1(at);
             p1 = tail1(at + 1u);
             p2 = tail1(at + 2u);
             p3 = tail1(at + 3u);
+            p4 = tail1(at + 4u);
+            p5 = tail1(at + 5u);
+            p6 = tail1(at + 6u);
+            p7 = tail1(at + 7u);
         }
     }
     ALAC_DEV void commit(W& wv) {
         wv.ring_write4(fill & (RING - 1u), __builtin_bswap32(p0), __builtin_bswap32(p1), __builtin_bswap32(p2),
                        __builtin_bswap32(p3));
-        fill += 4u;
+        wv.ring_write4((fill + 4u) & (RING - 1u), __builtin_bswap32(p4), __builtin_bswap32(p5), __builtin_bswap32(p6),
+                       __builtin_bswap32(p7));
+        fill += 8u;
         pend = false;
     }
     /* channel start: synchronous prefill from the block holding the (biased) position */
     ALAC_DEV void start(W& wv, uint32_t posb) {
         const uint32_t ni = posb >> 5;
-        fill = ni & ~3u;
+        fill = ni & ~7u;
         pend = false;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            load4(fill);
+#pragma nounroll
+        for (int b = 0; b < 3; ++b) {
+            load8(fill);
             commit(wv);
         }
         reseek(wv, posb);
@@ -259,11 +270,11 @@ struct RingRd {
     ALAC_DEV void reseek(W& wv, uint32_t posb) {
         widx = posb >> 5;
         /* a slow-path step (escape code + zero-run code) can eat more than one dword, more than tick() puts
-         * back: top the ring up on the spot whenever it runs low. Plain steps take <= 32 bits (prefix + 1 + k,
-         * k <= 23), which the 4 dwords per 4 steps of tick() cover. Positions are < 2^29 bits here (a live lane
+         * back: top the ring up on the spot whenever it runs low: up to seven plain steps (<= 26 bits each) may follow
+         * before the next top-up, and the cache reads two dwords ahead. Positions are < 2^29 bits here (a live lane
          * stays below max_pos + 66), so the loop ends. */
         while (fill < widx + 12u) {
-            if (!pend) load4(fill);
+            if (!pend) load8(fill);
             commit(wv);
         }
         w0 = wv.ring_read(widx & (RING - 1u));
@@ -284,11 +295,11 @@ struct RingRd {
         widx = ni;
         w2 = wv.ring_read((ni + 2u) & (RING - 1u));
     }
-    /* every 4th step, wave-uniform */
+    /* every 8th step, wave-uniform */
     ALAC_DEV void tick(W& wv) {
         if (pend) commit(wv);
-        if (fill + 4u <= widx + RING) {
-            load4(fill);
+        if (fill + 8u <= widx + RING) {
+            load8(fill);
             pend = true;
         }
     }
@@ -312,11 +323,13 @@ struct RegLane {
     ALAC_DEV uint32_t upos() const { return pos - rd.bias; } /* the stream position as the reference counts it */
 };
 
-/* `near` for the steps up to the next top-up (at most 4 from step i on): a plain step takes at most 8 + 1 + 16 bits
- * (lean_config), four of them 100; the channel's last sample is among the next four when i + 4 >= ns_live */
+/* `near` for the steps up to the next top-up (at most 8 from step i on): a plain step takes at most 8 + 1 + 16 bits
+ * (lean_config), one with an inline escape code (gol_step) at most 32: eight of them 256; the channel's last sample is
+ * among the next eight when i + 8 >= ns_live */
+constexpr uint32_t GOL_TICK = 8; /* steps per ring top-up */
 template <class W>
 ALAC_DEV uint32_t gol_near(const RegLane<W>& s, uint32_t i, uint32_t ns_live) {
-    return ALAC_SUBSAT(s.pos + 128u, s.max_pos) | ALAC_SUBSAT(i + 5u, ns_live) | s.zmode;
+    return ALAC_SUBSAT(s.pos + 32u * GOL_TICK, s.max_pos) | ALAC_SUBSAT(i + GOL_TICK + 1u, ns_live) | s.zmode;
 }
 
 /* The rare part of DynDecomp (golomb.go:167-247) for one lane: the lane's last samples and everything behind them,
@@ -400,8 +413,8 @@ ALAC_DEV uint32_t golomb_slow(const B& bits, RegLane<W>& s, uint32_t size, uint3
         s.mean = mean;
         s.zmode = zmode;
         s.zrem = zrem;
-        /* the steps up to the next top-up: at most three (gol_near) */
-        s.near = ALAC_SUBSAT(pos + bias + 128u, s.max_pos) | ALAC_SUBSAT(i + 5u, ns_live) | zmode;
+        /* the steps up to the next top-up: at most seven (gol_near) */
+        s.near = ALAC_SUBSAT(pos + bias + 32u * GOL_TICK, s.max_pos) | ALAC_SUBSAT(i + GOL_TICK + 1u, ns_live) | zmode;
         return ndq;
     }
     s.err = err;
@@ -695,18 +708,28 @@ ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_
      * chain wait for the store's round trip; issued right after it, it has four steps to drain */
     uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
     uint32_t i = 0;
-    for (; i + 4u <= n_it; i += 4u) { /* four steps per ring top-up, straight-line */
-        s.rd.tick(wv);
-        s.near = gol_near(s, i, ns_live);
+    auto four = [&]() { /* four steps, straight-line; the four before them go to the row first (see above) */
         if (keep && go && i != 0u) ALAC_STORE4(res_row + (i - 4u), (int32_t)h0, (int32_t)h1, (int32_t)h2, (int32_t)h3);
         h0 = gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i, my_ns, ns_live);
         h1 = gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i + 1u, my_ns, ns_live);
         h2 = gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i + 2u, my_ns, ns_live);
         h3 = gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i + 3u, my_ns, ns_live);
+        i += 4u;
+    };
+    while (i + GOL_TICK <= n_it) { /* eight steps per ring top-up */
+        s.rd.tick(wv);
+        s.near = gol_near(s, i, ns_live);
+#pragma nounroll
+        for (uint32_t h = 0; h < GOL_TICK; h += 4u) four();
+    }
+    if (i + 4u <= n_it) {
+        s.rd.tick(wv);
+        s.near = gol_near(s, i, ns_live);
+        four();
     }
     if (keep && go && i != 0u) ALAC_STORE4(res_row + (i - 4u), (int32_t)h0, (int32_t)h1, (int32_t)h2, (int32_t)h3);
     for (; i < n_it; ++i) {
-        if ((i & 3u) == 0) {
+        if ((i & (GOL_TICK - 1u)) == 0) {
             s.rd.tick(wv);
             s.near = gol_near(s, i, ns_live);
         }

@@ -4,10 +4,9 @@
  * largest variant, so the sample widths are separate kernels — a handle only ever launches the ones of its own
  * width — and the units compile in parallel.
  */
-/* the gated kind (k_decode_body.inc): 26 KB of LDS per pair (64-byte PCM pieces, 16-dword bitstream rings) and at most
+/* the gated kind (k_decode_body.inc): 26 KB of LDS per pair (64-byte PCM pieces) and at most
  * 168 registers, so that six pairs share a CU */
 #define ALAC_LDS_ROWS 32
-#define ALAC_LDS_RING 16
 #include "alac_gpu.h"
 
 #define ALAC_DECODE_KERNEL alac_decode_16g
