@@ -82,6 +82,15 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     constexpr bool DO_C = (ROLE == ROLE_C || ROLE == ROLE_BOTH) && EC;
     constexpr bool EMIT_A = (EA || EC) && LAST && !RAW; /* the samples leave wave B through the queue */
     constexpr bool DO_EMIT = EMIT_A ? (EC ? DO_C : DO_A) : DO_B;
+    /* FWD: with a writer wave, what the PCM of a pair needs from memory — the U samples, the shift bytes of the 3-byte
+     * block writer — is still fetched by the predictor wave and handed on through the queue (rows 2 CH .. and 3 CH ..).
+     * A wave's memory counter retires in issue order, loads and stores alike: a writer that fetched them itself would
+     * wait, at every load, for the PCM stores it issued before (24-bit pairs: 820 ticks per step in the writer against
+     * 430 in the other two). The predictor wave stores nothing in this phase. */
+#ifndef ALAC_FWD
+#define ALAC_FWD 0 /* measured (round 3): 16-bit pairs 2.36 -> 2.45 ms, 24-bit pairs 4.04 -> 3.78 (two waves: 3.52): not kept */
+#endif
+    constexpr bool FWD = ALAC_FWD != 0 && EMIT_A && EC && OUT == OUT_STEREO;
     constexpr uint32_t CH = EMIT_A ? DUO_CHUNK / 2u : DUO_CHUNK;
     const uint32_t na = GEN ? na_rt : (uint32_t)NA;
     uint32_t kb = cfg.kb;
@@ -232,13 +241,71 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
         for (int t = NR; t >= 1; --t) hb[t] = hb[t - 1];
         hb[0] = (uint32_t)o ^ BIAS;
         if (!LAST) *wv.u_row(i) = o; /* dead lanes write their own unused cell */
-        else if (EMIT_A) wv.rq_write(buf, CH + j, o);
+        else if (EMIT_A) {
+            wv.rq_write(buf, CH + j, o);
+            if (FWD) wv.rq_write(buf, 2u * CH + j, u); /* the U sample rides along (see FWD) */
+        }
         else emit(i, o, u, sw, jj, fp);
     };
+    constexpr bool PK3 = CPE && LAST && !F16 && !RAW && !EMIT_A;      /* ... in the predictor wave */
+    constexpr bool PK3C = CPE && LAST && !F16 && !RAW && EMIT_A && EC; /* ... in the writer wave */
+    const bool sb8 = (PK3 || PK3C) && !wv.any(ns != 0u && sb != 8u);
+    const bool sb0 = (PK3 || PK3C) && !wv.any(ns != 0u && sb != 0u);
+    const bool pk3 = (PK3 || PK3C) && bps == 3u && (sb8 || sb0);
+    const uint32_t sh_byte = shift_pos >> 3, sh_bit = shift_pos & 7u;
+    /* four frames of a 3-byte pair from their V samples vv, U samples uu and the 12 bytes fetched around their eight
+     * shift bytes: unmix (matrix.go:40-41 / :50-51, as in emit()), shift merge (:129-132) or the 20-bit shift (:77-78),
+     * six dwords into the stager */
+    auto pk3_block = [&](uint32_t rowq, const int32_t (&vv4)[4], const int32_t (&uu4)[4], uint32_t g0, uint32_t g1, uint32_t g2) {
+        /* the eight shift bytes of the block: stream bits sh_bit .. sh_bit + 64 of the 12 bytes fetched */
+        const uint32_t w0 = (uint32_t)(((((uint64_t)g0) << 32) | g1) << sh_bit >> 32);
+        const uint32_t w1 = (uint32_t)(((((uint64_t)g1) << 32) | g2) << sh_bit >> 32);
+        uint32_t lq[4], rq[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const int32_t vv = vv4[j];
+            const int32_t mv = NARROW ? ALAC_MUL24(mix_res, vv) : (int32_t)((uint32_t)mix_res * (uint32_t)vv);
+            int32_t l = uu4[j] + (int32_t)((uint32_t)vv & nzm) - (mv >> mix_sh);
+            int32_t r = (int32_t)((((uint32_t)(l - vv)) & nzm) | ((uint32_t)vv & ~nzm));
+            if (sb8) { /* matrix.go:129-132 */
+                const uint32_t w = j < 2u ? w0 : w1;
+                const uint32_t sl = (j & 1u) ? (w >> 8) & 0xffu : w >> 24;
+                const uint32_t sr = (j & 1u) ? w & 0xffu : (w >> 16) & 0xffu;
+                l = (int32_t)(((uint32_t)l << 8) | sl);
+                r = (int32_t)(((uint32_t)r << 8) | sr);
+            } else if (cfg.bit_depth == 20) { /* matrix.go:77-78 */
+                l = (int32_t)((uint32_t)l << 4);
+                r = (int32_t)((uint32_t)r << 4);
+            }
+            lq[j] = (uint32_t)l;
+            rq[j] = (uint32_t)r;
+        }
+        /* L0 L0 L0 R0 | R0 R0 L1 L1 | L1 R1 R1 R1, twice */
+        const uint32_t d0 = (lq[0] & 0xffffffu) | (rq[0] << 24);
+        const uint32_t d1 = ((rq[0] >> 8) & 0xffffu) | (lq[1] << 16);
+        const uint32_t d2 = ((lq[1] >> 16) & 0xffu) | (rq[1] << 8);
+        const uint32_t d3 = (lq[2] & 0xffffffu) | (rq[2] << 24);
+        const uint32_t d4 = ((rq[2] >> 8) & 0xffffu) | (lq[3] << 16);
+        const uint32_t d5 = ((lq[3] >> 16) & 0xffu) | (rq[3] << 8);
+        /* a lane whose frames end inside the block (a partial frame) keeps the whole dwords of its
+         * 6, 12 or 18 bytes; an odd count leaves two bytes for st_tail, as the generic packer would */
+        const uint32_t nv = umin(ALAC_SUBSAT(ns, rowq), 4u);
+        const uint32_t nby = nv * 6u;
+        wv.st_push6_n(d0, d1, d2, d3, d4, d5, nby >> 2);
+        if (nby & 2u) {
+            pk_acc = (nv == 1u ? d1 : d4) & 0xffffu;
+            pk_n = 2u;
+        }
+        wv.st_step();
+    };
+    const uint32_t sstep_b = (CPE ? 2u : 1u) * sb;
+    const uint32_t steady_end = (n_it / CH) * CH; /* whole chunks end here */
     /* A (EMIT_A): inputs of the chunk it writes, requested before the Golomb work of the iteration */
     int32_t sq_v[CH], u_v[CH];
     uint64_t sw_v[CH];
     const uint32_t sstep_a = (CPE ? 2u : 1u) * sb;
+    uint32_t g_v[CH / 4u][3] = {}; /* 3-byte pairs: the 12 bytes around each block's shift bytes */
+    auto whole_pk3 = [&](uint32_t c) { return PK3C && pk3 && (c + 1u) * CH <= n_it; }; /* wave-uniform */
     auto fetch_chunk = [&](uint32_t c) {
         const uint32_t buf = c & 1u;
 #pragma unroll
@@ -251,30 +318,56 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             }
             if (i < n_it) { /* scalar: rows past n_it do not exist in the tile */
                 sq_v[j] = wv.rq_read(buf, CH + j);
+                if (FWD) u_v[j] = wv.rq_read(buf, 2u * CH + j);
                 if (!EC) {
                     if (CPE) u_v[j] = *wv.u_row(i);
                     if (merge_any) sw_v[j] = bits.window_raw(shift_pos + i * sstep_a);
                 }
             }
         }
+        if (FWD && PK3C && whole_pk3(c) && sb8) {
+#pragma unroll
+            for (uint32_t q = 0; q < CH / 4u; ++q)
+#pragma unroll
+                for (uint32_t k = 0; k < 3u; ++k) g_v[q][k] = (uint32_t)wv.rq_read(buf, 3u * CH + 3u * q + k);
+        }
     };
-    /* the writer wave: what a chunk needs from memory (U samples, shift values) does not come from wave B, so it is
-     * asked for a whole iteration ahead */
+    /* the writer wave: what a chunk needs from memory (U samples, shift values) is asked for a whole iteration ahead
+     * (unless the predictor wave hands it on: FWD) */
     int32_t u_n[CH];
     uint64_t sw_n[CH];
+    uint32_t g_n[CH / 4u][3] = {};
     auto fetch_mem_ahead = [&](uint32_t c) {
+        const bool blocks = whole_pk3(c);
 #pragma unroll
         for (uint32_t j = 0; j < CH; ++j) {
             const uint32_t i = c * CH + j;
             u_n[j] = 0;
             sw_n[j] = 0;
             if (i < n_it) {
-                if (CPE) u_n[j] = *wv.u_row(i);
-                if (merge_any) sw_n[j] = bits.window_raw(shift_pos + i * sstep_a);
+                if (CPE && !FWD) u_n[j] = *wv.u_row(i);
+                if (merge_any && !blocks) sw_n[j] = bits.window_raw(shift_pos + i * sstep_a);
             }
+        }
+        if (!FWD && PK3C && blocks && sb8) {
+#pragma unroll
+            for (uint32_t q = 0; q < CH / 4u; ++q) bits.load12(sh_byte + 2u * (c * CH + 4u * q), g_n[q][0], g_n[q][1], g_n[q][2]);
         }
     };
     auto emit_chunk = [&](uint32_t c) {
+        if (PK3C && whole_pk3(c)) { /* the writer wave, 3-byte pairs, a whole chunk: two blocks of four frames */
+#pragma unroll
+            for (uint32_t q = 0; q < CH / 4u; ++q) {
+                int32_t vv4[4], uu4[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    vv4[j] = sq_v[4u * q + j];
+                    uu4[j] = u_v[4u * q + j];
+                }
+                pk3_block(c * CH + 4u * q, vv4, uu4, g_v[q][0], g_v[q][1], g_v[q][2]);
+            }
+            return;
+        }
 #pragma unroll
         for (uint32_t j = 0; j < CH; ++j) {
             const uint32_t i = c * CH + j;
@@ -296,7 +389,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
      * reads from HBM) then has eight steps to arrive instead of four. */
     constexpr uint32_t UN = (NARROW && (((F16 || !LAST || RAW || EMIT_A) && NR <= ALAC_DUO_UN8_MAX) ||
                                         NR <= (UN8W ? 8 : ALAC_DUO_UN8_WIDE_MAX))) ? 8u : 4u;
-    constexpr bool HBM_IN = LAST && !RAW && !EMIT_A; /* the writer runs here and reads the U tile / shift bytes */
+    constexpr bool HBM_IN = (LAST && !RAW && !EMIT_A) || FWD; /* this wave reads the U tile / shift bytes (to write, or to hand on) */
     /* role B fed from memory (split pipeline's predictor pass: W::kResMem): the residuals of a group are requested one
      * group ahead, like the U samples of the wide writers */
     constexpr bool RMEM = W::kResMem && ROLE == ROLE_B;
@@ -315,15 +408,8 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
      * instead of 64-bit shifts, three byte permutes per two frames instead of the generic packer's selects
      * (BASELINE config c). All live lanes must agree on the shift width (a wave of 24-bit packets with bytesShifted 2
      * among them takes the generic writer). */
-    constexpr bool PK3 = CPE && LAST && !F16 && !RAW && !EMIT_A;
     constexpr uint32_t NSUB = UN / 4u; /* blocks of four frames in a group */
-    const bool sb8 = PK3 && !wv.any(ns != 0u && sb != 8u);
-    const bool sb0 = PK3 && !wv.any(ns != 0u && sb != 0u);
-    const bool pk3 = PK3 && bps == 3u && (sb8 || sb0);
-    const uint32_t sh_byte = shift_pos >> 3, sh_bit = shift_pos & 7u;
     uint32_t gpre[NSUB][3] = {};
-    const uint32_t sstep_b = (CPE ? 2u : 1u) * sb;
-    const uint32_t steady_end = (n_it / CH) * CH; /* whole chunks end here */
     auto prefetch_group = [&](uint32_t row0) {
         pre_row = row0;
 #pragma unroll
@@ -333,7 +419,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             if (CPE) upre[j] = *wv.u_row(row0 + j);
             if (merge_any && !pk3) spre[j] = bits.window_raw(shift_pos + (row0 + j) * sstep_b);
         }
-        if (PK3 && pk3 && sb8) {
+        if ((PK3 || (FWD && PK3C)) && pk3 && sb8) {
 #pragma unroll
             for (uint32_t q = 0; q < NSUB; ++q) bits.load12(sh_byte + 2u * (row0 + 4u * q), gpre[q][0], gpre[q][1], gpre[q][2]);
         }
@@ -386,54 +472,26 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
 #pragma unroll
                         for (uint32_t j = 0; j < UN; ++j) dpre[j] = wv.rq_read(buf, g + UN + j);
                     }
+                    if (FWD && PK3C && pk3 && sb8) { /* the shift bytes of the group's blocks, for the writer wave */
+#pragma unroll
+                        for (uint32_t q = 0; q < NSUB; ++q)
+#pragma unroll
+                            for (uint32_t k = 0; k < 3u; ++k) wv.rq_write(buf, 3u * CH + 3u * (g / 4u + q) + k, (int32_t)gq[q][k]);
+                    }
                     if (PK3 && pk3) {
 #pragma unroll
                         for (uint32_t q = 0; q < NSUB; ++q) {
-                            /* the eight shift bytes of the block: stream bits sh_bit .. sh_bit + 64 of the 12 bytes fetched */
-                            const uint32_t g0 = gq[q][0], g1 = gq[q][1], g2 = gq[q][2];
-                            const uint32_t w0 = (uint32_t)(((((uint64_t)g0) << 32) | g1) << sh_bit >> 32);
-                            const uint32_t w1 = (uint32_t)(((((uint64_t)g1) << 32) | g2) << sh_bit >> 32);
-                            uint32_t lq[4], rq[4];
+                            int32_t vv4[4], uu4[4];
 #pragma unroll
                             for (uint32_t j = 0; j < 4u; ++j) {
                                 const int32_t vv = predict_q(dv[4u * q + j], wrap);
 #pragma unroll
                                 for (int t = NR; t >= 1; --t) hb[t] = hb[t - 1];
                                 hb[0] = (uint32_t)vv ^ BIAS;
-                                /* matrix.go:40-41 / :50-51, as in emit() */
-                                const int32_t mv = NARROW ? ALAC_MUL24(mix_res, vv) : (int32_t)((uint32_t)mix_res * (uint32_t)vv);
-                                int32_t l = uv[4u * q + j] + (int32_t)((uint32_t)vv & nzm) - (mv >> mix_sh);
-                                int32_t r = (int32_t)((((uint32_t)(l - vv)) & nzm) | ((uint32_t)vv & ~nzm));
-                                if (sb8) { /* matrix.go:129-132 */
-                                    const uint32_t w = j < 2u ? w0 : w1;
-                                    const uint32_t sl = (j & 1u) ? (w >> 8) & 0xffu : w >> 24;
-                                    const uint32_t sr = (j & 1u) ? w & 0xffu : (w >> 16) & 0xffu;
-                                    l = (int32_t)(((uint32_t)l << 8) | sl);
-                                    r = (int32_t)(((uint32_t)r << 8) | sr);
-                                } else if (cfg.bit_depth == 20) { /* matrix.go:77-78 */
-                                    l = (int32_t)((uint32_t)l << 4);
-                                    r = (int32_t)((uint32_t)r << 4);
-                                }
-                                lq[j] = (uint32_t)l;
-                                rq[j] = (uint32_t)r;
+                                vv4[j] = vv;
+                                uu4[j] = uv[4u * q + j];
                             }
-                            /* L0 L0 L0 R0 | R0 R0 L1 L1 | L1 R1 R1 R1, twice */
-                            const uint32_t d0 = (lq[0] & 0xffffffu) | (rq[0] << 24);
-                            const uint32_t d1 = ((rq[0] >> 8) & 0xffffu) | (lq[1] << 16);
-                            const uint32_t d2 = ((lq[1] >> 16) & 0xffu) | (rq[1] << 8);
-                            const uint32_t d3 = (lq[2] & 0xffffffu) | (rq[2] << 24);
-                            const uint32_t d4 = ((rq[2] >> 8) & 0xffffu) | (lq[3] << 16);
-                            const uint32_t d5 = ((lq[3] >> 16) & 0xffu) | (rq[3] << 8);
-                            /* a lane whose frames end inside the block (a partial frame) keeps the whole dwords of its
-                             * 6, 12 or 18 bytes; an odd count leaves two bytes for st_tail, as the generic packer would */
-                            const uint32_t nv = umin(ALAC_SUBSAT(ns, row0 + 4u * q), 4u);
-                            const uint32_t nby = nv * 6u;
-                            wv.st_push6_n(d0, d1, d2, d3, d4, d5, nby >> 2);
-                            if (nby & 2u) {
-                                pk_acc = (nv == 1u ? d1 : d4) & 0xffffu;
-                                pk_n = 2u;
-                            }
-                            wv.st_step();
+                            pk3_block(row0 + 4u * q, vv4, uu4, gq[q][0], gq[q][1], gq[q][2]);
                         }
                         continue;
                     }
@@ -479,6 +537,16 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             run_groups(wrap_yes{});
             return;
         }
+        if (FWD && PK3C && whole_pk3(c) && sb8) { /* a whole chunk outside the steady state: its shift bytes, on the spot */
+#pragma unroll
+            for (uint32_t q = 0; q < CH / 4u; ++q) {
+                uint32_t g0, g1, g2;
+                bits.load12(sh_byte + 2u * (c * CH + 4u * q), g0, g1, g2);
+                wv.rq_write(buf, 3u * CH + 3u * q, (int32_t)g0);
+                wv.rq_write(buf, 3u * CH + 3u * q + 1u, (int32_t)g1);
+                wv.rq_write(buf, 3u * CH + 3u * q + 2u, (int32_t)g2);
+            }
+        }
 #pragma nounroll
         for (uint32_t j = 0; j < CH; ++j) {
             const uint32_t i = c * CH + j;
@@ -489,7 +557,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             if (i == 0 || (GEN && na == 0)) o = del;
             else if (i <= na || (GEN && na == 31)) o = sext_cs(del + (int32_t)(hb[0] ^ BIAS), chan_shift);
             else o = predict(del, wrap_yes{});
-            put(buf, j, i, o, (CPE && !EMIT_A) ? *wv.u_row(i) : 0,
+            put(buf, j, i, o, (CPE && (!EMIT_A || FWD)) ? *wv.u_row(i) : 0,
                 (!EMIT_A && merge_any) ? bits.window_raw(shift_pos + i * sstep) : 0ull, 0u, fp_no{});
             if (LAST && !EMIT_A) wv.st_step();
             if (FP_OK && i + 1u == ns) (void)wv.st_finish(); /* see run_groups */
@@ -521,11 +589,19 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             if (c >= 2u) {
 #pragma unroll
                 for (uint32_t j = 0; j < CH; ++j) {
-                    u_v[j] = u_n[j];
+                    if (!FWD) u_v[j] = u_n[j];
                     sw_v[j] = sw_n[j];
                 }
+                if (!FWD) {
+#pragma unroll
+                    for (uint32_t q = 0; q < CH / 4u; ++q) {
+                        g_v[q][0] = g_n[q][0];
+                        g_v[q][1] = g_n[q][1];
+                        g_v[q][2] = g_n[q][2];
+                    }
+                }
             }
-            if (c >= 1u && c <= nch) fetch_mem_ahead(c - 1u);
+            if ((merge_any || !FWD) && c >= 1u && c <= nch) fetch_mem_ahead(c - 1u);
             if (c >= 2u) {
                 fetch_chunk(c - 2u);
                 emit_chunk(c - 2u);

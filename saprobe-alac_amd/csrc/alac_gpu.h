@@ -188,8 +188,12 @@ static __shared__ __attribute__((aligned(16))) uint32_t s_ring[kWave * kRingStri
 /* residual queue of the wave pair (alac_duo.h), A -> B, double-buffered chunks */
 constexpr uint32_t kQ = alac::DUO_CHUNK;
 /* rows per buffer: a chunk of residuals A -> B; where another wave writes the PCM (alac_duo.h: EMIT_A) half a chunk of
- * residuals and half a chunk of samples B -> writer */
-constexpr uint32_t kQRows = alac::DUO_CHUNK;
+ * residuals and half a chunk of samples B -> writer; with a writer wave (ALAC_LDS_QROWS 32 in k_dec*t.hip) also half a
+ * chunk of U samples and six rows of shift bytes (alac_duo.h: FWD) */
+#ifndef ALAC_LDS_QROWS
+#define ALAC_LDS_QROWS ALAC_DUO_CHUNK
+#endif
+constexpr uint32_t kQRows = ALAC_LDS_QROWS;
 static __shared__ int32_t s_rq[2 * kQRows * kWave];
 
 /* U hand-off tile of one wave: frame_length rows of 64 cells and one spare row (the single-wave decoders read one
@@ -390,7 +394,8 @@ struct PairArgs {
 };
 #define ALAC_DECLARE_DECODE(NAME) __global__ void NAME(PairArgs);
 /* the wave pair over the regular packets, one kernel per class (sample width x channel width) */
-ALAC_DECLARE_DECODE(alac_decode_16) ALAC_DECLARE_DECODE(alac_decode_16g) ALAC_DECLARE_DECODE(alac_decode_16t) ALAC_DECLARE_DECODE(alac_decode_24) ALAC_DECLARE_DECODE(alac_decode_32)
+ALAC_DECLARE_DECODE(alac_decode_16) ALAC_DECLARE_DECODE(alac_decode_16g) ALAC_DECLARE_DECODE(alac_decode_16t)
+ALAC_DECLARE_DECODE(alac_decode_24t) ALAC_DECLARE_DECODE(alac_decode_24) ALAC_DECLARE_DECODE(alac_decode_32)
 ALAC_DECLARE_DECODE(alac_decode_w24) ALAC_DECLARE_DECODE(alac_decode_w32)
 #undef ALAC_DECLARE_DECODE
 __global__ void alac_chan_predict(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,

@@ -361,12 +361,13 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
                    (uint32_t*)((uint8_t*)plan + plan_claims_offset()), ppw, dec->n_cu, 0u};
         const uint32_t slots = (uint32_t)max_waves(dec, n, ppw);
         auto pairs = [&](auto kernel, uint32_t roles = 2u) { hipLaunchKernelGGL(kernel, dim3(slots), dim3(roles * kWave), 0, dec->stream, a); };
+        /* one round or less of narrow slots: workgroups of entropy, predictor and writer waves (k_dec*t.hip); more: wave
+         * pairs. (slots is an upper bound: a partly filled wave per key present; the kernels decide on the real count) */
+        const bool one_round = (size_t)slots <= (size_t)4 * dec->n_cu + 2 * 18 * 18 + 8;
         switch (dec->cfg.bit_depth) {
             case 16:
                 a.cap = pair_capacity(alac_decode_16g);
-                /* one round or less: workgroups of entropy, predictor and writer waves (k_dec16t.hip); more: wave pairs */
-                /* (slots is an upper bound: a partly filled wave per key present; the kernels decide on the real count) */
-                if ((size_t)slots <= (size_t)4 * dec->n_cu + 18 * 18 + 8) pairs(alac_decode_16t, 3u);
+                if (one_round) pairs(alac_decode_16t, 3u);
                 pairs(alac_decode_16);
                 /* as many workgroups as the device holds at once: they share the slots out among themselves */
                 if ((size_t)slots > (size_t)4 * dec->n_cu && a.cap > 4u)
@@ -378,6 +379,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
                 pairs(alac_decode_w32); /* chanBits > 23 only exists at 24 and 32 bits (without their usual shift bytes) */
                 break;
             default: /* 20 and 24 */
+                if (one_round && dec->cfg.num_channels == 2) pairs(alac_decode_24t, 3u);
                 pairs(alac_decode_24);
                 if (dec->cfg.bit_depth == 24) pairs(alac_decode_w24);
         }

@@ -68,7 +68,7 @@ struct HostWave {
     }
     uint32_t ring_read(uint32_t slot) const { return ring[slot]; }
     /* residual queue of alac_duo.h: one lane, both roles played by the same caller, so the barriers are no-ops */
-    int32_t rq[2][alac::DUO_CHUNK] = {{0}};
+    int32_t rq[2][2 * alac::DUO_CHUNK] = {{0}};
     void rq_write(uint32_t buf, uint32_t j, int32_t v) { rq[buf][j] = v; }
     int32_t rq_read(uint32_t buf, uint32_t j) const { return rq[buf][j]; }
     void duo_sync() {}
@@ -152,9 +152,9 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
                 if (dc.bit_depth == 16)
                     status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH, -1, 16, true>(wv, dc, key, true, p, sizes[i], avail, o, &frames_out[i]);
                 else if (dc.bit_depth == 32)
-                    status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH, -1, 32>(wv, dc, key, true, p, sizes[i], avail, o, &frames_out[i]);
+                    status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH, -1, 32, true>(wv, dc, key, true, p, sizes[i], avail, o, &frames_out[i]);
                 else
-                    status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH, -1, 24>(wv, dc, key, true, p, sizes[i], avail, o, &frames_out[i]);
+                    status[i] = alac::decode_regular_duo<HostWave, alac::ROLE_BOTH, -1, 24, true>(wv, dc, key, true, p, sizes[i], avail, o, &frames_out[i]);
                 continue;
             }
         }

@@ -9,10 +9,11 @@ pkg = importlib.import_module("saprobe-alac_amd")
 synth = importlib.import_module("saprobe-alac_amd.synth")
 synth.build()
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-cfg = pkg.PacketConfig(FrameLength=4096, BitDepth=16, NumChannels=2)
+DEPTH = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+cfg = pkg.PacketConfig(FrameLength=4096, BitDepth=DEPTH, NumChannels=2)
 b = synth.gen_batch(cfg, P, profile=0, first_index=0, threads=16)
 dev = torch.device("cuda", 0)
-stride = 4096 * 4
+stride = 4096 * 2 * pkg.bytes_per_sample(DEPTH)
 d_blob = torch.from_numpy(b.blob).to(dev)
 d_off = torch.from_numpy(b.offsets.astype(np.int64)).to(dev)
 d_sz = torch.from_numpy(b.sizes.astype(np.int32)).to(dev)
