@@ -55,7 +55,7 @@ enum { ROLE_A = 0, ROLE_B = 1, ROLE_BOTH = 2, ROLE_C = 3 };
  * mode (per lane) != 0: the delta pre-pass of decoder.go:307-309 runs on the residual stream first (split
  * pipeline only: regular packets have mode 0).
  */
-template <class W, class B, int NA, int OUT, int ROLE, bool F16, bool NARROW, bool EA, bool UN8W = false, bool EC = false>
+template <class W, class B, int NA, int OUT, int ROLE, bool F16, bool NARROW, bool EA, bool UN8W = false, bool EC = false, int WMODE = 0>
 ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, uint32_t size, uint32_t ns,
                         uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits, int32_t mix_res,
                         uint32_t mix_sh, uint32_t na_rt, uint32_t shift_pos, uint32_t sb, uint32_t mode) {
@@ -127,17 +127,24 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
         return mode != 0 ? dd : del;
     };
     /* wrap: the int16 coefficient wrap of unpcBlockGeneral (predictor.go:664,675) is applied in this step */
+    /* wide channels (chanBits > 23): 24 and 25 bits take the mask arithmetic with 32-bit products (predict_narrow_core:
+     * MID), only 32 and 33 the literal form. WMODE 1: the caller's streams are 24 bits deep, their wide channels have
+     * 24 or 25 bits, always; otherwise the wave looks at its lanes once per phase. */
+    constexpr bool MID_ONLY = !NARROW && WMODE == 1;
+    const bool mid = !NARROW && (MID_ONLY || !wv.any(ns != 0u && chan_bits > 25u));
     auto predict = [&](int32_t del, auto wrap) -> int32_t {
         constexpr bool WR = decltype(wrap)::value;
         if (NARROW) return predict_narrow<NR, GEN, WR, !RAW>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
-        return predict_wide<NR, GEN, WR>(coef, hb, na, del, den_shift, den_half, chan_shift);
+        if (MID_ONLY || mid) return predict_narrow<NR, GEN, WR, !RAW, true>(coef, hb, na, del, den_shift, den_half, rnd_neg, chan_shift);
+        if constexpr (!MID_ONLY) return predict_wide<NR, GEN, WR>(coef, hb, na, del, den_shift, den_half, chan_shift);
+        return 0;
     };
     /* the same from what the queue / the row holds */
     auto predict_q = [&](int32_t x, auto wrap) -> int32_t {
         constexpr bool WR = decltype(wrap)::value;
         if (!QND) return predict(x, wrap);
         if (NARROW) return predict_narrow_nd<NR, GEN, WR, !RAW>(coef, hb, na, (uint32_t)x, den_shift, den_half, rnd_neg, chan_shift);
-        return predict_wide<NR, GEN, WR>(coef, hb, na, gol_unfold((uint32_t)x), den_shift, den_half, chan_shift);
+        return predict(gol_unfold((uint32_t)x), wrap);
     };
     using wrap_yes = std::integral_constant<bool, WRAP>;
     using wrap_no = std::integral_constant<bool, false>;
@@ -622,13 +629,13 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
 ALAC_DEV constexpr bool duo_emit_in_a(uint32_t na, bool cpe) { return !cpe && na >= 5u && na <= 16u; }
 
 /* the order switch is scalar: NA is wave-uniform by construction of the waves. Role A never looks at the order. */
-template <class W, int OUT, int ROLE, bool F16, bool NARROW = true, bool UN8W = false, bool EC = false, class B>
+template <class W, int OUT, int ROLE, bool F16, bool NARROW = true, bool UN8W = false, bool EC = false, int WMODE = 0, class B>
 ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits, RegLane<W>& s, uint32_t size,
                            uint32_t ns, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift, uint32_t chan_bits,
                            int32_t mix_res, uint32_t mix_sh, uint32_t shift_pos, uint32_t sb, uint32_t mode = 0u) {
 #define ALAC_DUO_CASE(N)                                                                                              \
     case N:                                                                                                           \
-        duo_phase<W, B, N, OUT, ROLE, F16, NARROW, CAN_EA && duo_emit_in_a(N, OUT == OUT_STEREO), UN8W, EC>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, \
+        duo_phase<W, B, N, OUT, ROLE, F16, NARROW, CAN_EA && duo_emit_in_a(N, OUT == OUT_STEREO), UN8W, EC, WMODE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, \
                                                                        den_shift, chan_bits, mix_res, mix_sh, na,     \
                                                                        shift_pos, sb, mode);                          \
         break;
@@ -642,8 +649,8 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits,
                 return;
             }
         }
-        duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, false, false, EC>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
-                                                                  mix_res, mix_sh, na, shift_pos, sb, mode);
+        duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, false, false, EC, WMODE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
+                                                                         mix_res, mix_sh, na, shift_pos, sb, mode);
         return;
     }
     switch (na) {
@@ -664,8 +671,8 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits,
         ALAC_DUO_CASE(15)
         ALAC_DUO_CASE(16)
         default:
-            duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, false, false, EC>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
-                                                                      mix_res, mix_sh, na, shift_pos, sb, mode);
+            duo_phase<W, B, 0, OUT, ROLE, F16, NARROW, false, false, EC, WMODE>(wv, cfg, bits, s, size, ns, n_it, hdr_pos, den_shift, chan_bits,
+                                                                             mix_res, mix_sh, na, shift_pos, sb, mode);
             break;
     }
 #undef ALAC_DUO_CASE
@@ -684,6 +691,7 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
                                     uint32_t avail, uint8_t* out, uint32_t* frames_out) {
     constexpr bool DO_A = ROLE == ROLE_A || ROLE == ROLE_BOTH, DO_B = ROLE == ROLE_B || ROLE == ROLE_BOTH;
     constexpr bool DO_C = ROLE == ROLE_C || ROLE == ROLE_BOTH;
+    constexpr int WM = DEPTH_SEL == 24 ? 1 : 0; /* 24-bit streams: wide channels have 24 or 25 bits, never more (duo_phase) */
     const BitsT<false> bits{pkt, size, avail}; /* regular packets hold at least 12 bytes (classify_regular) */
     const bool cpe = cfg.num_channels == 2;
     /* chanBits > 23: predict_wide. WIDE_SEL 0 / 1: the caller only ever passes keys of that kind (the other half is
@@ -737,8 +745,8 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
         else duo_phase_na<W, OUT_MONO, ROLE, false, true, false, EC>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
     }
     if constexpr (WIDE_SEL != 0) if (wide) {
-        if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
-        else duo_phase_na<W, OUT_MONO, ROLE, false, false>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
+        if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false, false, false, false, WM>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
+        else duo_phase_na<W, OUT_MONO, ROLE, false, false, false, false, WM>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, 0, 0, shift_pos, sb);
     }
     uint32_t err_chan = 0;
     /* ---- V ---- */
@@ -752,7 +760,7 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
         s.pb = (cfg.pb * ((hv >> 5) & 7u)) / 4u;
         if (DO_A) s.rd.start(wv, (live && s.err == 0) ? s.pos : s.rd.bias);
         if constexpr (WIDE_SEL != 0) if (wide)
-            duo_phase_na<W, OUT_STEREO, ROLE, false, false>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
+            duo_phase_na<W, OUT_STEREO, ROLE, false, false, false, false, WM>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);
         /* DEPTH_SEL 16 / 24 / 32: the caller's configuration has that sample width (24 stands for both 3-byte depths) */
         if constexpr (WIDE_SEL != 1) if (!wide) {
             if constexpr (DEPTH_SEL == 0 || DEPTH_SEL == 16) if (cfg.bit_depth == 16)

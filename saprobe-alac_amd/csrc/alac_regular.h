@@ -285,6 +285,21 @@ struct RingRd {
         const uint32_t r = posb & 31u;
         return (uint32_t)(((((uint64_t)w0) << 32) | w1) << r >> 32);
     }
+    /* (cold) 64 stream bits from posb, MSB first, out of the LDS ring: what the slow path looks at. It used to ask the
+     * stateless reader, i.e. global memory, a trip of a microsecond or two for every rare step; streams that are all
+     * rare steps (24- and 32-bit without shift bytes: incompressible low bytes, every other code an escape code) were
+     * bound by that. The ring is topped up first when it does not reach three dwords behind the position. */
+    ALAC_DEV uint64_t window64(W& wv, uint32_t posb) {
+        const uint32_t ni = posb >> 5, r = posb & 31u;
+        while (fill < ni + 4u) {
+            if (!pend) load8(fill);
+            commit(wv);
+        }
+        const uint64_t a = wv.ring_read(ni & (RING - 1u)), b = wv.ring_read((ni + 1u) & (RING - 1u));
+        const uint64_t c = wv.ring_read((ni + 2u) & (RING - 1u));
+        const uint64_t hi = (a << 32) | b;
+        return r ? (hi << r) | (c >> (32u - r)) : hi;
+    }
     /* the cache moves by 0 or 1 dword per step (the slow path reseeks); the move is a bit mask, not a compare;
      * w2 is re-read from LDS every step */
     ALAC_DEV void slide(W& wv, uint32_t posb) {
@@ -338,7 +353,7 @@ ALAC_DEV uint32_t gol_near(const RegLane<W>& s, uint32_t i, uint32_t ns_live) {
  * golomb.go:206-209). Works on local copies and writes the lane state back once (stores into the state from several
  * exits make the compiler keep it in scratch memory). ns_live: the lane's sample count, 0 once it has failed. */
 template <class W, class B>
-ALAC_DEV uint32_t golomb_slow(const B& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
+ALAC_DEV uint32_t golomb_slow(W& wv, const B& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
                               uint32_t chan_bits, uint32_t i, uint32_t ns, uint32_t& ns_live) {
     if (i >= ns_live) { /* nothing left to decode: park the lane (it looks like one inside an endless zero run) */
         s.zrem = GOL_PARK;
@@ -355,14 +370,14 @@ ALAC_DEV uint32_t golomb_slow(const B& bits, RegLane<W>& s, uint32_t size, uint3
         uint32_t m = mean >> 9;
         const uint32_t k = umin(31u - clz32(m + 3u), kb);
         m = (1u << k) - 1u;
-        const uint32_t w = (uint32_t)(bits.window(pos) >> 32);
+        const uint32_t w = (uint32_t)(s.rd.window64(wv, pos + bias) >> 32);
         uint32_t n = clz32(~w);
         if (n >= 9) { /* getStreamBits(bitPos+9, maxSize), golomb.go:184-186,86-108 */
             const uint32_t gpos = pos + 9u;
             const uint32_t gb = gpos & 7u;
             const bool five = chan_bits + gb > 32u;
             if ((gpos >> 3) > size || (five && (gpos >> 3) >= size)) err = ST_MALFORMED;
-            const uint64_t w2 = bits.window(gpos);
+            const uint64_t w2 = s.rd.window64(wv, gpos + bias);
             if (chan_bits == 0) n = 0;
             else if (chan_bits <= 32) n = (uint32_t)(w2 >> (64u - chan_bits));
             else n = (uint32_t)(w2 >> 31) & ((2u << gb) - 1u); /* numBits 33: only byte 5 survives (golomb.go:90-99) */
@@ -389,7 +404,7 @@ ALAC_DEV uint32_t golomb_slow(const B& bits, RegLane<W>& s, uint32_t size, uint3
                 if ((pos >> 3) > size) { /* dynGet's read32bit, golomb.go:115 */
                     err = ST_MALFORMED;
                 } else {
-                    const uint32_t wz = (uint32_t)(bits.window(pos) >> 32);
+                    const uint32_t wz = (uint32_t)(s.rd.window64(wv, pos + bias) >> 32);
                     const uint32_t pre = clz32(~wz);
                     uint32_t rl;
                     if (pre >= 9) {
@@ -449,6 +464,7 @@ ALAC_DEV uint32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, u
      * but that takes a few instructions instead of golomb_slow. */
     const uint32_t o_pos = s.pos, o_mean = s.mean, o_zrem = s.zrem;
     RingRd<W>& rd = s.rd;
+    const uint32_t o_w0 = rd.w0, o_w1 = rd.w1, o_w2 = rd.w2; /* the window cache before the step (rare path only) */
 #ifdef ALAC_PAD_A /* experiment: what an instruction more in the entropy step costs */
     {
         uint32_t pad_ = i;
@@ -507,19 +523,29 @@ ALAC_DEV uint32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, u
      * in there */
     if (ALAC_UNLIKELY(wv.any(rare != 0u))) {
         if (rare != 0u) {
-            /* ESC: an escape code and nothing else (one sample in two thousand of music has one, i.e. one step in thirty
-             * of a wave of 64): for chan_bits <= 23 the whole code lies in the window already, the value is the
-             * chan_bits bits behind the nine ones (golomb.go:184-186); the lane is not within reach of the packet's end
-             * (near), so nothing of getStreamBits' bounds can fail. Everything else, and an escape that turns out
-             * to be more than that (n > 0xffff, a zero run behind it), takes golomb_slow from the lane's old state. */
+            /* ESC: the two rare cases that need no more than the window cache held before this step (96 stream bits from
+             * the position's dword on), for a lane that is not within reach of the packet's end (near), so that nothing
+             * of the reference's bounds can fail. (1) An escape code (one sample in two thousand of music has one, i.e.
+             * one step in thirty of a wave of 64; every other sample of a 24-bit stream without shift bytes): the
+             * value is the chan_bits <= 32 bits behind the nine ones (golomb.go:184-186, getStreamBits :86-108).
+             * (2) n > 0xffff: the mean is clamped (golomb.go:216-218). Everything else, and a zero run behind either
+             * (mean * 4 < 512), takes golomb_slow from the lane's old state. */
             bool done = false;
-            if (ESC && esc != 0u && s.near == 0u && chan_bits <= 23u) {
-                const uint32_t n2 = ALAC_BFE(w, 23u - chan_bits, chan_bits);
-                const uint32_t m2 = ALAC_MULU24(s.pb, n2) + mt;
-                if (n2 <= 0xffffu && m2 >= 128u) {
-                    s.pos = o_pos + 9u + chan_bits;
-                    s.mean = m2;
-                    ndq = n2;
+            if (ESC && s.near == 0u) {
+                if (esc != 0u && chan_bits <= 32u && chan_bits != 0u) {
+                    const uint64_t hi = (((uint64_t)o_w0) << 32) | o_w1;
+                    const uint64_t w64 = r ? (hi << r) | ((uint64_t)o_w2 >> (32u - r)) : hi; /* 64 stream bits from the position */
+                    const uint32_t n2 = (uint32_t)((w64 << 9) >> (64u - chan_bits));
+                    const uint32_t m2 = n2 > 0xffffu ? 0xffffu : s.pb * n2 + mt;
+                    if (m2 >= 128u) {
+                        s.pos = o_pos + 9u + chan_bits;
+                        s.mean = m2;
+                        /* golomb.go:206-209 computes (nd + 1) >> 1 in uint32: see golomb_slow */
+                        ndq = n2 == 0xffffffffu ? 0u : n2;
+                        done = true;
+                    }
+                } else if (esc == 0u && (n >> 16) != 0u) {
+                    s.mean = 0xffffu; /* position and countdown as the plain step left them; no zero run: 0xffff * 4 >= 512 */
                     done = true;
                 }
             }
@@ -527,7 +553,7 @@ ALAC_DEV uint32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, u
                 s.pos = o_pos;
                 s.mean = o_mean;
                 s.zrem = o_zrem;
-                ndq = golomb_slow(bits, s, size, kb, wb, chan_bits, i, ns, ns_live);
+                ndq = golomb_slow(wv, bits, s, size, kb, wb, chan_bits, i, ns, ns_live);
             }
             rd.reseek(wv, s.pos); /* the window cache afresh */
         }
@@ -544,7 +570,13 @@ ALAC_DEV int32_t gol_unfold(uint32_t nd) { return (int32_t)((nd >> 1) ^ (0u - (n
  * denShift) tap after tap and tap j adapts while something of D0 is left. chanBits <= 23 keeps q < 2^23 and
  * t_j < 2^27: nothing wraps, which is what makes this equal to the reference's signed countdown.
  * GEN: the wave-uniform order na on NR = 16 register taps; WRAP: int16 coefficients (predictor.go:664,675). */
-template <int NR, bool GEN, bool WRAP, bool CB_POS = false>
+/* MID (round 3): chanBits 24 and 25 — 24-bit streams without shift bytes, 32-bit streams with one shift byte — in the
+ * same mask arithmetic with 32-bit products (two instructions where the 24-bit multiply-add is one) and a sticky `go`:
+ * |e| < 2^26 and q < 2^26, so a single t_j = (na-j) * q < 2^30 cannot wrap, but their sum can (136 * 2^26), and the
+ * countdown must not come back up through the wrap: once a tap stopped adapting, none below it does (the reference
+ * breaks out of its loop there). Until then nothing has wrapped and the normalised countdown equals the reference's
+ * signed one. The literal form (predict_wide) is left for chanBits 32 and 33, whose differences wrap in int32. */
+template <int NR, bool GEN, bool WRAP, bool CB_POS = false, bool MID = false>
 ALAC_DEV int32_t predict_narrow_core(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1], uint32_t na, int32_t del, uint32_t sgnm,
                                      uint32_t nsg, int32_t rem, uint32_t den_shift, int32_t den_half, uint32_t rnd_neg,
                                      uint32_t chan_shift) {
@@ -574,6 +606,7 @@ ALAC_DEV int32_t predict_narrow_core(int32_t (&coef)[NR], const uint32_t (&hb)[N
      * (independent instructions back to back): 2.45 ms vs 3.01 ms on the benchmark batch — with a partner wave on the
      * SIMD filling the gaps, short live ranges matter more than the distance between dependent instructions. */
     int32_t acc = den_half;
+    int32_t gos = 1;
 #pragma unroll
     for (int j = NR - 1; j >= 0; --j) {
         if (GEN && (uint32_t)j >= na) continue; /* scalar branch: taps the order does not have */
@@ -598,12 +631,17 @@ ALAC_DEV int32_t predict_narrow_core(int32_t (&coef)[NR], const uint32_t (&hb)[N
         const int32_t e = (int32_t)(hb[j] - topb);            /* out[i-1-j] - top; the bias cancels */
         const uint32_t ae = ALAC_SAD(topb, hb[j], rnd);       /* |e| + rounding */
         const int32_t sg = ALAC_SIGN(e);
-        acc = ALAC_MAD24(coef[j], e, acc);                    /* uses coef[j] before its update */
+        acc = MID ? (int32_t)((uint32_t)acc + (uint32_t)coef[j] * (uint32_t)e)
+                  : ALAC_MAD24(coef[j], e, acc);              /* uses coef[j] before its update */
         const uint32_t q = ae >> den_shift;
-        const int32_t go = ALAC_CLAMP01(rem);                 /* tap j adapts while the budget is not used up */
+        int32_t go = ALAC_CLAMP01(rem);                       /* tap j adapts while the budget is not used up */
+        if (MID) {
+            go &= gos;
+            gos = go;
+        }
         /* coefficient step sign(del) * -sign(top - h_j) = sign(del) * sign(e): (sign(e) ^ sgnm) + nsg */
         const int32_t delta = (int32_t)ALAC_XAD(sg, sgnm, nsg);
-        rem = ALAC_MSUB24(rem, q, na - (uint32_t)j);
+        rem = MID ? (int32_t)((uint32_t)rem - q * (na - (uint32_t)j)) : ALAC_MSUB24(rem, q, na - (uint32_t)j);
         const int32_t cj = ALAC_MAD24(delta, go, coef[j]);
         coef[j] = WRAP ? (int32_t)(int16_t)cj : cj;           /* predictor.go:664,675 */
 #endif
@@ -614,11 +652,11 @@ ALAC_DEV int32_t predict_narrow_core(int32_t (&coef)[NR], const uint32_t (&hb)[N
 }
 
 /* the step from the residual itself ... */
-template <int NR, bool GEN, bool WRAP, bool CB_POS = false>
+template <int NR, bool GEN, bool WRAP, bool CB_POS = false, bool MID = false>
 ALAC_DEV int32_t predict_narrow(int32_t (&coef)[NR], const uint32_t (&hb)[NR + 1], uint32_t na, int32_t del,
                                 uint32_t den_shift, int32_t den_half, uint32_t rnd_neg, uint32_t chan_shift) {
     const uint32_t sgnm = (uint32_t)(del >> 31), nsg = (uint32_t)del >> 31;
-    return predict_narrow_core<NR, GEN, WRAP, CB_POS>(coef, hb, na, del, sgnm, nsg, (int32_t)(((uint32_t)del ^ sgnm) + nsg), den_shift,
+    return predict_narrow_core<NR, GEN, WRAP, CB_POS, MID>(coef, hb, na, del, sgnm, nsg, (int32_t)(((uint32_t)del ^ sgnm) + nsg), den_shift,
                                                       den_half, rnd_neg, chan_shift);
 }
 /* ... and from what the entropy wave queues, nd = n + zmode (gol_step): sign, magnitude and residual all come out of
