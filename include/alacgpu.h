@@ -114,7 +114,11 @@ typedef struct alacgpu_decoder alacgpu_decoder;
 
 /* NewPacketDecoder (decoder.go:90). device = HIP ordinal; one stream per handle. */
 int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out);
+/* A destroyed handle's streams, events and (moderately sized) device / pinned buffers are kept for the next
+ * alacgpu_create on the same device: a file decoder makes and drops a handle per file (decode.go:50-80), and building
+ * one from nothing costs several times the decode of a short file. alacgpu_trim() frees what is kept. */
 void alacgpu_destroy(alacgpu_decoder* dec);
+void alacgpu_trim(void);
 
 /* (*PacketDecoder).Format (decoder.go:112). */
 int alacgpu_get_format(const alacgpu_decoder* dec, alacgpu_format* fmt);

@@ -188,6 +188,7 @@ def csrc_sha256():
 _EXPORTS = {
     "alacgpu_create": (ctypes.c_int, [ctypes.POINTER(PacketConfig), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "alacgpu_destroy": (None, [ctypes.c_void_p]),
+    "alacgpu_trim": (None, []),
     "alacgpu_get_format": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PCMFormat)]),
     "alacgpu_frame_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "alacgpu_decode_packet": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,

@@ -436,84 +436,19 @@ bool is_pinned(const void* p) {
 
 } /* namespace */
 
-extern "C" {
+/* ---- handles between uses -------------------------------------------------------------------------------------
+ * A file decoder makes a handle, decodes a window or two and destroys it (decode.go:50-80 / stream.py); building one
+ * from nothing costs three streams, the events, the CU census with its two synchronisations, and at the first decode a
+ * dozen hipMalloc and the pinned staging buffers — 15 ms, where the decode of a 10-second file takes 3. Destroyed
+ * handles therefore keep their device-side belongings in a small per-process pool (a few per device, big buffers
+ * dropped) and alacgpu_create takes one from there when it can. alacgpu_trim() empties the pool. */
+namespace {
+std::mutex g_pool_mu;
+std::vector<alacgpu_decoder*> g_pool;
+constexpr size_t kPoolPerDevice = 4;
+constexpr size_t kPoolBufCap = (size_t)256 << 20; /* a pooled handle keeps no single buffer larger than this */
 
-int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out) {
-    if (!cfg || !out) {
-        set_err("null argument");
-        return ALACGPU_E_ARG;
-    }
-    *out = nullptr;
-    const int bps = bytes_per_sample(cfg->bit_depth);
-    if (bps == 0) { /* decoder.go:91-93 */
-        set_err("invalid configuration: alac: unsupported bit depth: %d", (int)cfg->bit_depth);
-        return ALACGPU_E_CONFIG;
-    }
-    if (cfg->num_channels < 1 || cfg->num_channels > 8) {
-        set_err("invalid configuration: NumChannels %d outside 1..8", (int)cfg->num_channels);
-        return ALACGPU_E_CONFIG;
-    }
-    if (cfg->frame_length == 0 || cfg->frame_length > (1u << 24)) {
-        set_err("invalid configuration: FrameLength %u", cfg->frame_length);
-        return ALACGPU_E_CONFIG;
-    }
-    HIP_TRY(hipSetDevice(device));
-    alacgpu_decoder* d = new (std::nothrow) alacgpu_decoder();
-    if (!d) {
-        set_err("out of memory");
-        return ALACGPU_E_ARG;
-    }
-    d->cfg = *cfg;
-    d->device = device;
-    d->frame_bytes = (size_t)cfg->frame_length * cfg->num_channels * (size_t)bps;
-    d->dev_cfg = alac::DevCfg{cfg->frame_length, cfg->bit_depth, cfg->num_channels, cfg->pb, cfg->mb, cfg->kb,
-                              (uint32_t)bps, 0u};
-    d->launches = 0;
-    d->pool = nullptr;
-    d->il_threads = 64;
-    {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
-        d->n_cu = cus > 0 ? (uint32_t)cus : 256u;
-    }
-    if (const char* e = getenv("ALACGPU_IL_THREADS")) {
-        const int v = atoi(e);
-        if (v == 64 || v == 128 || v == 256) d->il_threads = (uint32_t)v;
-    }
-    d->chunk_bytes = (size_t)192 << 20;
-    if (const char* e = getenv("ALACGPU_CHUNK_MB")) {
-        const long v = atol(e);
-        if (v >= 1 && v <= 65536) d->chunk_bytes = (size_t)v << 20;
-    }
-    d->stream = d->s_in = d->s_out = nullptr;
-    for (uint32_t i = 0; i < kTimingSlots; i++) d->ev_start[i] = d->ev_stop[i] = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_in, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_out, hipStreamNonBlocking);
-    for (uint32_t i = 0; i < kTimingSlots && e == hipSuccess; i++) {
-        e = hipEventCreate(&d->ev_start[i]);
-        if (e == hipSuccess) e = hipEventCreate(&d->ev_stop[i]);
-    }
-    for (int k = 0; k < kSlots && e == hipSuccess; k++) {
-        e = hipEventCreateWithFlags(&d->slots[k].ev_in, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->slots[k].ev_k, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->slots[k].ev_out, hipEventDisableTiming);
-    }
-    if (e != hipSuccess) {
-        set_err("stream/event creation failed: %s", hipGetErrorString(e));
-        alacgpu_destroy(d);
-        return ALACGPU_E_HIP;
-    }
-    if (int rc = cu_numbers(d)) {
-        alacgpu_destroy(d);
-        return rc;
-    }
-    *out = d;
-    return ALACGPU_E_OK;
-}
-
-void alacgpu_destroy(alacgpu_decoder* d) {
-    if (!d) return;
+void really_destroy(alacgpu_decoder* d) {
     (void)hipSetDevice(d->device);
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     if (d->s_in) (void)hipStreamSynchronize(d->s_in);
@@ -540,6 +475,138 @@ void alacgpu_destroy(alacgpu_decoder* d) {
     if (d->s_in) (void)hipStreamDestroy(d->s_in);
     if (d->s_out) (void)hipStreamDestroy(d->s_out);
     delete d;
+}
+
+/* the per-configuration part of a handle (everything else survives in the pool) */
+void configure(alacgpu_decoder* d, const alacgpu_config* cfg, int bps) {
+    d->cfg = *cfg;
+    d->frame_bytes = (size_t)cfg->frame_length * cfg->num_channels * (size_t)bps;
+    d->dev_cfg = alac::DevCfg{cfg->frame_length, cfg->bit_depth, cfg->num_channels, cfg->pb, cfg->mb, cfg->kb,
+                              (uint32_t)bps, 0u};
+    d->launches = 0;
+    d->il_threads = 64;
+    if (const char* e = getenv("ALACGPU_IL_THREADS")) {
+        const int v = atoi(e);
+        if (v == 64 || v == 128 || v == 256) d->il_threads = (uint32_t)v;
+    }
+    d->chunk_bytes = (size_t)192 << 20;
+    if (const char* e = getenv("ALACGPU_CHUNK_MB")) {
+        const long v = atol(e);
+        if (v >= 1 && v <= 65536) d->chunk_bytes = (size_t)v << 20;
+    }
+}
+} /* namespace */
+
+extern "C" {
+
+int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out) {
+    if (!cfg || !out) {
+        set_err("null argument");
+        return ALACGPU_E_ARG;
+    }
+    *out = nullptr;
+    const int bps = bytes_per_sample(cfg->bit_depth);
+    if (bps == 0) { /* decoder.go:91-93 */
+        set_err("invalid configuration: alac: unsupported bit depth: %d", (int)cfg->bit_depth);
+        return ALACGPU_E_CONFIG;
+    }
+    if (cfg->num_channels < 1 || cfg->num_channels > 8) {
+        set_err("invalid configuration: NumChannels %d outside 1..8", (int)cfg->num_channels);
+        return ALACGPU_E_CONFIG;
+    }
+    if (cfg->frame_length == 0 || cfg->frame_length > (1u << 24)) {
+        set_err("invalid configuration: FrameLength %u", cfg->frame_length);
+        return ALACGPU_E_CONFIG;
+    }
+    HIP_TRY(hipSetDevice(device));
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i]->device == device) {
+                alacgpu_decoder* d = g_pool[i];
+                g_pool.erase(g_pool.begin() + (long)i);
+                configure(d, cfg, bps);
+                *out = d;
+                return ALACGPU_E_OK;
+            }
+    }
+    alacgpu_decoder* d = new (std::nothrow) alacgpu_decoder();
+    if (!d) {
+        set_err("out of memory");
+        return ALACGPU_E_ARG;
+    }
+    d->device = device;
+    d->pool = nullptr;
+    configure(d, cfg, bps);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
+        d->n_cu = cus > 0 ? (uint32_t)cus : 256u;
+    }
+    d->stream = d->s_in = d->s_out = nullptr;
+    for (uint32_t i = 0; i < kTimingSlots; i++) d->ev_start[i] = d->ev_stop[i] = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_in, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_out, hipStreamNonBlocking);
+    for (uint32_t i = 0; i < kTimingSlots && e == hipSuccess; i++) {
+        e = hipEventCreate(&d->ev_start[i]);
+        if (e == hipSuccess) e = hipEventCreate(&d->ev_stop[i]);
+    }
+    for (int k = 0; k < kSlots && e == hipSuccess; k++) {
+        e = hipEventCreateWithFlags(&d->slots[k].ev_in, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->slots[k].ev_k, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->slots[k].ev_out, hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        set_err("stream/event creation failed: %s", hipGetErrorString(e));
+        really_destroy(d);
+        return ALACGPU_E_HIP;
+    }
+    if (int rc = cu_numbers(d)) {
+        really_destroy(d);
+        return rc;
+    }
+    *out = d;
+    return ALACGPU_E_OK;
+}
+
+void alacgpu_destroy(alacgpu_decoder* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    /* nothing of this handle's last call may still be running when its belongings go to the next owner */
+    bool ok = hipStreamSynchronize(d->stream) == hipSuccess && hipStreamSynchronize(d->s_in) == hipSuccess &&
+              hipStreamSynchronize(d->s_out) == hipSuccess;
+    if (ok) {
+        for (int k = 0; k < kSlots; k++) d->slots[k].busy = false;
+        DevBuf* bufs[] = {&d->scratch_u, &d->scratch_g, &d->plan, &d->cls, &d->perm, &d->sizes_ws, &d->cd, &d->pd,
+                          &d->plan2, &d->keys2, &d->perm2, &d->rows};
+        for (DevBuf* b : bufs)
+            if (b->cap > kPoolBufCap) b->release();
+        for (int k = 0; k < kSlots; k++) {
+            Slot& s = d->slots[k];
+            if (s.d_in.cap > kPoolBufCap) s.d_in.release();
+            if (s.d_out.cap > kPoolBufCap) s.d_out.release();
+            if (s.h_in.cap > kPoolBufCap) s.h_in.release();
+            if (s.h_out.cap > kPoolBufCap) s.h_out.release();
+        }
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        size_t same = 0;
+        for (alacgpu_decoder* p : g_pool) same += p->device == d->device ? 1u : 0u;
+        if (same < kPoolPerDevice) {
+            g_pool.push_back(d);
+            return;
+        }
+    }
+    really_destroy(d);
+}
+
+void alacgpu_trim(void) {
+    std::vector<alacgpu_decoder*> all;
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        all.swap(g_pool);
+    }
+    for (alacgpu_decoder* d : all) really_destroy(d);
 }
 
 int alacgpu_get_format(const alacgpu_decoder* d, alacgpu_format* fmt) {
