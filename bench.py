@@ -48,6 +48,21 @@ def parse():
     return ap.parse_args()
 
 
+def pair_kernel(depth, ch, packets):
+    """Which of the pair kernels decodes a batch of regular packets (k_decode_body.inc: three_waves / pair_gated decide
+    on the device from the number of 64-packet wave slots; 256 CUs assumed here, for the name only)."""
+    slots = (packets + 63) // 64
+    if depth == 16:
+        if slots <= 1024:
+            return "alac_decode_16t (entropy, predictor and writer wave per 64 packets)"
+        return "alac_decode_16 / alac_decode_16g (wave pairs; the gated twin between the multiples of 4 x CUs slots)"
+    if depth == 32:
+        return "alac_decode_32"
+    if ch == 2 and slots <= (1024 if depth == 20 else 512):
+        return "alac_decode_24t (entropy, predictor and writer wave per 64 packets)"
+    return "alac_decode_24"
+
+
 def host_threads():
     try:
         n = len(os.sched_getaffinity(0))
@@ -254,8 +269,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None,
                          "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload and this source)") if traffic else None,
-                         "kernel": ("alac_decode_%s" % {16: "16 (alac_decode_16g between the rounds)", 20: "24", 24: "24", 32: "32"}[depth]) if ch <= 2
-                         else "alac_scan + alac_chan_predict + alac_interleave",
+                         "kernel": pair_kernel(depth, ch, P) if ch <= 2 else "alac_scan + alac_chan_predict + alac_interleave",
                          "kernel_ms": round(kernel_ms, 4), "kernel_ms_is": "HIP events on the handle's stream around all kernels of one decode (sort pre-pass included)",
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu, "bit_exact": bit_exact, "gen_seconds": round(gen_s, 2), "host_entry": host_entry,
