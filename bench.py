@@ -54,12 +54,12 @@ def pair_kernel(depth, ch, packets):
     slots = (packets + 63) // 64
     if depth == 16:
         if slots <= 1024:
-            return "alac_decode_16t (entropy, predictor and writer wave per 64 packets)"
+            return "alac_decode_16q (entropy, predictor and writer wave per 64 packets; two predictor waves for long predictors in small batches)"
         return "alac_decode_16 / alac_decode_16g (wave pairs; the gated twin between the multiples of 4 x CUs slots)"
     if depth == 32:
         return "alac_decode_32"
     if ch == 2 and slots <= (1024 if depth == 20 else 512):
-        return "alac_decode_24t (entropy, predictor and writer wave per 64 packets)"
+        return "alac_decode_24q (entropy, predictor and writer wave per 64 packets)"
     return "alac_decode_24"
 
 

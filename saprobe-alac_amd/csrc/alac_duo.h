@@ -622,6 +622,174 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     if (!LAST) wv.duo_sync_mem();                  /* the U tile is complete before anyone loads from it */
 }
 
+/*
+ * Role B on TWO LANES PER PACKET (round 3): the predictor waves of the four-wave workgroups (k_dec16q.hip), for keys with
+ * a long predictor. A predictor step costs ten instructions per tap and a workgroup's step is its longest wave's: with
+ * twelve taps role B needs 128 instructions against the entropy wave's 66, and the 5 % of the benchmark's packets that
+ * have them kept the whole batch waiting (65 536 packets: 2.43 ms, 2.04 ms without them). Such a workgroup gets a second
+ * predictor wave; each of the two holds 32 of the 64 packets, a packet's taps spread over a DPP pair: lane q holds taps
+ * q T .. q T + T - 1 (T = ceil(order / 2)), the prediction is the sum over the pair, what the upper lane's taps take off
+ * the adaptation countdown (alac_regular.h: predict_narrow_core) reaches the lower lane by one DPP move, the history
+ * moves by renaming and one DPP move, the sample enters at lane 0. ~10 T + 20 instructions per step. The order is
+ * wave-uniform (one key per workgroup), so top = out[i - 1 - order] sits at a fixed place of lane 1.
+ * Protocol, queue and hand-off rows exactly as role B of duo_phase() in a workgroup with a writer wave (EC): residuals
+ * come as n + zmode, U samples go to the hand-off tile, the samples of the last channel to rows CH.. of the queue buffer
+ * for the writer wave. wv.lane is the packet's COLUMN (its lane in the entropy and writer waves), q the lane's number in
+ * its pair. chanBits <= 23 only.
+ */
+template <class W, class B, int T, int OUT>
+ALAC_DEV void duo_phase_lanes(W& wv, const B& bits, uint32_t q, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift,
+                              uint32_t chan_bits, uint32_t na) {
+    constexpr bool LAST = OUT != OUT_UTILE;
+    constexpr uint32_t CH = LAST ? DUO_CHUNK / 2u : DUO_CHUNK;
+    constexpr uint32_t BIAS = 0x80000000u;
+    const bool wraps = order_wraps16(na); /* wave-uniform */
+    const uint32_t chan_shift = 32u - chan_bits;
+    const int32_t den_half = den_shift ? (int32_t)(1u << (den_shift - 1u)) : 0;
+    const int32_t dh0 = q == 0u ? den_half : 0; /* the rounding term enters the sum once */
+    const uint32_t rnd_neg = (1u << den_shift) - 1u;
+    const uint32_t q0m = q == 0u ? 0xffffffffu : 0u;
+    int32_t coef[T], wneg[T], m[T];
+    uint32_t g[T + 1]; /* g[t] = out[i - 1 - (q T + t)] ^ BIAS */
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const uint32_t jt = q * (uint32_t)T + (uint32_t)t;
+        const bool have = jt < na;
+        coef[t] = have ? (int32_t)(int16_t)bits.get(hdr_pos + 16u + 16u * jt, 16) : 0;
+        wneg[t] = have ? -(int32_t)(na - jt) : 0;
+        m[t] = have ? 1 : 0;
+        g[t] = BIAS;
+    }
+    g[T] = BIAS;
+    int32_t prev = 0;
+    const bool top_last = na == 2u * (uint32_t)T; /* top = out[i - 1 - na]: lane 1's g[T] (g[T - 1] when the order is odd) */
+
+    /* one step: sample i from what the entropy wave queued (nd = n + zmode, golomb.go:206-209). PLAIN: i > order. */
+    auto step = [&](uint32_t i, uint32_t nd, auto plain_c, auto wrap_c) -> int32_t {
+        constexpr bool PLAIN = decltype(plain_c)::value, WR = decltype(wrap_c)::value;
+        const uint32_t topb = wv.pair_hi(top_last ? g[T] : g[T - 1]);
+        const uint32_t nsg = nd & 1u, sgnm = 0u - nsg, hm = nd >> 1;
+        const int32_t del = (int32_t)(hm ^ sgnm);
+        int32_t rem = (int32_t)(hm + nsg); /* |del| */
+        if (!PLAIN) {
+            if (i <= na) rem = 0; /* nothing adapts during the warm-up (wave-uniform) */
+        }
+        const uint32_t rnd = rnd_neg & sgnm;
+        int32_t acc = dh0, s = 0;
+        int32_t e[T], sg[T];
+        uint32_t qv[T];
+#pragma unroll
+        for (int t = T - 1; t >= 0; --t) {
+            e[t] = (int32_t)(g[t] - topb);
+            const uint32_t ae = ALAC_SAD(topb, g[t], rnd);
+            sg[t] = ALAC_SIGN(e[t]);
+            qv[t] = ae >> den_shift;
+            if (t != 0) {
+                acc = ALAC_MAD24(coef[t], e[t], acc);
+                s = ALAC_MAD24(qv[t], wneg[t], s);
+            } else { /* what the DPP moves read comes from instructions the compiler knows (it inserts their wait states) */
+                acc = ALAC_MUL24(coef[t], e[t]) + acc;
+                s = ALAC_MUL24((int32_t)qv[t], wneg[t]) + s;
+            }
+        }
+        rem += (int32_t)(wv.pair_hi((uint32_t)s) & q0m); /* minus what the upper lane's taps take away */
+#pragma unroll
+        for (int t = T - 1; t >= 0; --t) {
+            const int32_t go = ALAC_MED3_0(rem, m[t]);
+            const int32_t delta = (int32_t)ALAC_XAD(sg[t], sgnm, nsg);
+            rem = ALAC_MAD24(qv[t], wneg[t], rem);
+            int32_t cj = ALAC_MAD24(delta, go, coef[t]);
+            if (WR) cj = (int32_t)(int16_t)cj; /* predictor.go:664,675 */
+            coef[t] = cj;
+        }
+        const int32_t at = wv.pair_sum(acc);
+        int32_t o = ALAC_SEXT_BITS(del + (int32_t)(topb ^ BIAS) + (at >> den_shift), chan_bits);
+        if (!PLAIN) {
+            if (i == 0u) o = del; /* out[0] = pc1[0] */
+            else if (i <= na) o = sext_cs(del + prev, chan_shift); /* predictor.go:63-79 */
+        }
+        const uint32_t g0 = wv.pair_from_below(g[T - 1], (uint32_t)o ^ BIAS, q0m); /* the tap below a lane's first comes from the lane before */
+#pragma unroll
+        for (int t = T; t >= 1; --t) g[t] = g[t - 1];
+        g[0] = g0;
+        prev = o;
+        return o;
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    auto put = [&](uint32_t buf, uint32_t k, uint32_t i, int32_t o) {
+        if (!LAST) *wv.u_row(i) = o; /* both lanes of the pair store the same value to the packet's cell */
+        else wv.rq_write(buf, CH + k, o);
+    };
+    auto predict_chunk = [&](uint32_t cc) {
+        const uint32_t i0 = cc * CH, buf = cc & 1u;
+        const uint32_t nst = umin(CH, n_it - i0);
+        if (i0 > na && nst == CH) {
+            auto run = [&](auto wrap_c) {
+                uint32_t dv[CH];
+#pragma unroll
+                for (uint32_t k = 0; k < CH; ++k) dv[k] = (uint32_t)wv.rq_read(buf, k);
+#pragma unroll
+                for (uint32_t k = 0; k < CH; ++k) put(buf, k, i0 + k, step(i0 + k, dv[k], yes{}, wrap_c));
+            };
+            if (wraps) {
+                /* a coefficient moves by at most 1 per step: one that is further than a chunk away from the int16 limits
+                 * cannot wrap inside this chunk (predict_chunk of duo_phase) */
+                constexpr uint32_t TW = 32767u - CH;
+                uint32_t far = 0;
+#pragma unroll
+                for (int t = 0; t < T; ++t) far = umax(far, (uint32_t)coef[t] + TW);
+                if (wv.any(far > 2u * TW)) {
+                    run(yes{});
+                    return;
+                }
+            }
+            run(no{});
+            return;
+        }
+#pragma nounroll
+        for (uint32_t k = 0; k < nst; ++k) {
+            const uint32_t nd = (uint32_t)wv.rq_read(buf, k);
+            const int32_t o = wraps ? step(i0 + k, nd, no{}, yes{}) : step(i0 + k, nd, no{}, no{});
+            put(buf, k, i0 + k, o);
+        }
+    };
+    const uint32_t nch = (n_it + CH - 1u) / CH;
+    const uint32_t iters = nch + (LAST ? 2u : 1u);
+    for (uint32_t c = 0; c < iters; ++c) {
+        if (c >= 1u && c <= nch) predict_chunk(c - 1u);
+        wv.duo_sync();
+    }
+    if (!LAST) wv.duo_sync_mem(); /* the U tile is complete before anyone loads from it */
+}
+
+/* taps per lane by the (wave-uniform) order, 3..16 (duo_lanes_key) */
+template <class W, int OUT, class B>
+ALAC_DEV void duo_phase_lanes_na(W& wv, uint32_t na, const B& bits, uint32_t q, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift,
+                                 uint32_t chan_bits) {
+    switch ((na + 1u) / 2u) {
+        case 0:
+        case 1:
+        case 2: duo_phase_lanes<W, B, 2, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+        case 3: duo_phase_lanes<W, B, 3, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+        case 4: duo_phase_lanes<W, B, 4, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+        case 5: duo_phase_lanes<W, B, 5, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+        case 6: duo_phase_lanes<W, B, 6, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+        case 7: duo_phase_lanes<W, B, 7, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+        default: duo_phase_lanes<W, B, 8, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+    }
+}
+
+/* keys the two-lane predictor waves take: every order 3..16 (T = ceil(order / 2) >= 2 puts top at lane 1's g[T] or
+ * g[T - 1]) and the longer one at least `lanes_min` */
+ALAC_DEV bool duo_lanes_key(uint32_t key, bool cpe, uint32_t lanes_min) {
+    const uint32_t nu = (key >> 5) & 31u, nv = key & 31u;
+    if ((key & KEY_WIDE) != 0u || nu < 3u || nu > 16u) return false;
+    if (!cpe) return nu >= lanes_min;
+    if (nv < 3u || nv > 16u) return false;
+    return umax(nu, nv) >= lanes_min;
+}
+
 /* which wave writes the PCM of a channel with predictor order na: B's step grows by nine instructions per tap, A's
  * does not; for single channels the writer balances the pair better in A from order 5 on (mono 16-bit: 1.93 ->
  * 1.63 ms). Not for pairs: the writer then needs the U tile and the shift bytes from HBM, and in wave A every wait
@@ -686,9 +854,12 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits,
  */
 /* EC: the caller's workgroup has a third wave (ROLE_C) that writes the PCM of the narrow phases (duo_phase); its return
  * value and *frames_out mean nothing either. */
-template <class W, int ROLE, int WIDE_SEL = -1, int DEPTH_SEL = 0, bool EC = false>
+/* LANES: the caller is a predictor wave on two lanes per packet (duo_phase_lanes; wv.lane = the packet's column, q = the
+ * lane's number in its pair); ns_other: the frame count of the packet in the same column of the workgroup's other
+ * predictor wave, so that both agree with the entropy wave on the number of steps. */
+template <class W, int ROLE, int WIDE_SEL = -1, int DEPTH_SEL = 0, bool EC = false, bool LANES = false>
 ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
-                                    uint32_t avail, uint8_t* out, uint32_t* frames_out) {
+                                    uint32_t avail, uint8_t* out, uint32_t* frames_out, uint32_t q = 0u, uint32_t ns_other = 0u) {
     constexpr bool DO_A = ROLE == ROLE_A || ROLE == ROLE_BOTH, DO_B = ROLE == ROLE_B || ROLE == ROLE_BOTH;
     constexpr bool DO_C = ROLE == ROLE_C || ROLE == ROLE_BOTH;
     constexpr int WM = DEPTH_SEL == 24 ? 1 : 0; /* 24-bit streams: wide channels have 24 or 25 bits, never more (duo_phase) */
@@ -728,7 +899,17 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     const uint32_t chan_bits = cfg.bit_depth - 8u * bs + (cpe ? 1u : 0u);
     /* the 16- and 20-bit writers ignore the shift buffer (matrix.go:30,66) */
     const uint32_t sb = (cfg.bit_depth == 24 || cfg.bit_depth == 32) ? bs * 8u : 0u;
-    const uint32_t n_it = wv.max_u32(ns);
+    const uint32_t n_it = wv.max_u32(LANES ? umax(ns, ns_other) : ns);
+    if constexpr (LANES) {
+        static_assert(ROLE == ROLE_B && EC && WIDE_SEL == 0, "a predictor wave beside an entropy and a writer wave, narrow channels");
+        if (cpe) {
+            duo_phase_lanes_na<W, OUT_UTILE>(wv, na_u, bits, q, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits);
+            duo_phase_lanes_na<W, OUT_STEREO>(wv, na_v, bits, q, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits);
+        } else {
+            duo_phase_lanes_na<W, OUT_MONO>(wv, na_u, bits, q, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits);
+        }
+        return 0;
+    }
     /* the stager belongs to the wave that writes the PCM of the last channel (duo_emit_in_a) */
     const bool emit_a = !EC && !wide && duo_emit_in_a(cpe ? na_v : na_u, cpe);
     const bool writer = (EC && !wide) ? DO_C : (emit_a ? DO_A : DO_B);

@@ -93,6 +93,12 @@ __device__ __forceinline__ int32_t alac_sext_bits(int32_t x, uint32_t bits) {
 }
 #define ALAC_SEXT_BITS(x, bits) alac_sext_bits((int32_t)(x), (uint32_t)(bits))
 #define ALAC_MULU24(a, b) __umul24((unsigned)(a), (unsigned)(b))
+__device__ __forceinline__ int32_t alac_med3_0(int32_t x, int32_t m) {
+    int32_t r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(m));
+    return r;
+}
+#define ALAC_MED3_0(x, m) alac_med3_0((int32_t)(x), (int32_t)(m))
 #define ALAC_PICK(dst, src) asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(src))
 #define ALAC_OWN_REG(x) asm volatile("" : "+v"(x))
 typedef uint32_t alac_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -188,7 +194,7 @@ static __shared__ __attribute__((aligned(16))) uint32_t s_ring[kWave * kRingStri
 /* residual queue of the wave pair (alac_duo.h), A -> B, double-buffered chunks */
 constexpr uint32_t kQ = alac::DUO_CHUNK;
 /* rows per buffer: a chunk of residuals A -> B; where another wave writes the PCM (alac_duo.h: EMIT_A) half a chunk of
- * residuals and half a chunk of samples B -> writer; with a writer wave (ALAC_LDS_QROWS 32 in k_dec*t.hip) also half a
+ * residuals and half a chunk of samples B -> writer; with a writer wave and ALAC_FWD (ALAC_LDS_QROWS 32) also half a
  * chunk of U samples and six rows of shift bytes (alac_duo.h: FWD) */
 #ifndef ALAC_LDS_QROWS
 #define ALAC_LDS_QROWS ALAC_DUO_CHUNK
@@ -316,6 +322,14 @@ struct GpuWave {
     /* residual queue: row j of buffer buf holds step j of the chunk for all 64 lanes (conflict-free) */
     ALAC_DEV void rq_write(uint32_t buf, uint32_t j, int32_t v) { s_rq[(buf * kQRows + j) * kWave + lane] = v; }
     ALAC_DEV int32_t rq_read(uint32_t buf, uint32_t j) const { return s_rq[(buf * kQRows + j) * kWave + lane]; }
+    /* two lanes per packet (alac_duo.h: duo_phase_lanes): DPP moves inside every pair of neighbouring lanes. Their source
+     * must be the result of an instruction the compiler knows (not of inline asm): it inserts the wait states they need. */
+    ALAC_DEV uint32_t pair_hi(uint32_t x) const { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF5, 0xf, 0xf, false); } /* [1,1,3,3] */
+    ALAC_DEV int32_t pair_sum(int32_t x) const { return x + __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false); }            /* [1,0,3,2] */
+    /* lane 1 takes lane 0's x, lane 0 takes `fresh` (q0m: all ones in lane 0) */
+    ALAC_DEV uint32_t pair_from_below(uint32_t x, uint32_t fresh, uint32_t q0m) const {
+        return ALAC_BFI(q0m, fresh, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xA0, 0xf, 0xf, false)); /* [0,0,2,2] */
+    }
     /* chunk hand-over between the two waves of the workgroup: LDS traffic only, so outstanding global loads
      * (ring refills, U prefetch) and stores (U tile) are NOT waited for — __syncthreads() would drain them */
     ALAC_DEV void duo_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -391,11 +405,12 @@ struct PairArgs {
     uint32_t ppw;
     uint32_t n_cu; /* compute units of the device */
     uint32_t cap;  /* pairs one of them holds */
+    uint32_t lanes_min; /* four-wave workgroups (k_dec16q.hip): keys whose longer predictor has at least this many taps get two predictor waves */
 };
 #define ALAC_DECLARE_DECODE(NAME) __global__ void NAME(PairArgs);
 /* the wave pair over the regular packets, one kernel per class (sample width x channel width) */
-ALAC_DECLARE_DECODE(alac_decode_16) ALAC_DECLARE_DECODE(alac_decode_16g) ALAC_DECLARE_DECODE(alac_decode_16t)
-ALAC_DECLARE_DECODE(alac_decode_24t) ALAC_DECLARE_DECODE(alac_decode_24) ALAC_DECLARE_DECODE(alac_decode_32)
+ALAC_DECLARE_DECODE(alac_decode_16) ALAC_DECLARE_DECODE(alac_decode_16g) ALAC_DECLARE_DECODE(alac_decode_16q)
+ALAC_DECLARE_DECODE(alac_decode_24q) ALAC_DECLARE_DECODE(alac_decode_24) ALAC_DECLARE_DECODE(alac_decode_32)
 ALAC_DECLARE_DECODE(alac_decode_w24) ALAC_DECLARE_DECODE(alac_decode_w32)
 #undef ALAC_DECLARE_DECODE
 __global__ void alac_chan_predict(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,

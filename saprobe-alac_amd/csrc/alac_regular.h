@@ -108,6 +108,10 @@
 /* the low `bits` (1..31) of x, sign-extended: one v_bfe_i32 on the GPU (the compiler makes two shifts of it) */
 #define ALAC_SEXT_BITS(x, bits) ((int32_t)((uint32_t)(x) << (32u - (bits))) >> (32u - (bits)))
 #endif
+#ifndef ALAC_MED3_0
+/* 0 for x <= 0, else min(x, m): with m in {0, 1} "x is positive and m is set"; one v_med3_i32 on the GPU */
+#define ALAC_MED3_0(x, m) ((x) <= 0 ? 0 : ((x) < (m) ? (x) : (m)))
+#endif
 #ifndef ALAC_BFE
 /* (x >> off[4:0]) & ((1 << width[4:0]) - 1): v_bfe_u32 on the GPU */
 #define ALAC_BFE(x, off, width) ((((uint32_t)(x)) >> ((off) & 31u)) & ((1u << ((width) & 31u)) - 1u))

@@ -210,6 +210,7 @@ struct alacgpu_decoder {
     uint32_t n_cu;                                           /* compute units of the device */
     DevBuf cu_number;                                        /* PairArgs::cu_number */
     size_t chunk_bytes;                                      /* host entry: target bytes (in + out) per chunk */
+    uint32_t lanes_min;                                      /* PairArgs::lanes_min; above 16: no second predictor wave for any key */
 };
 
 namespace {
@@ -358,16 +359,16 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
          * kernel can hold (0: it has none); which of the twins works is decided on the device. */
         PairArgs a{c, d_blob, (uint64_t)blob_bytes, d_offsets, sz, (const uint32_t*)dec->perm.p, plan, d_out, (uint64_t)out_stride,
                    d_frames, d_status, (int32_t*)dec->scratch_u.p, (const uint32_t*)dec->cu_number.p,
-                   (uint32_t*)((uint8_t*)plan + plan_claims_offset()), ppw, dec->n_cu, 0u};
+                   (uint32_t*)((uint8_t*)plan + plan_claims_offset()), ppw, dec->n_cu, 0u, dec->lanes_min};
         const uint32_t slots = (uint32_t)max_waves(dec, n, ppw);
         auto pairs = [&](auto kernel, uint32_t roles = 2u) { hipLaunchKernelGGL(kernel, dim3(slots), dim3(roles * kWave), 0, dec->stream, a); };
-        /* one round or less of narrow slots: workgroups of entropy, predictor and writer waves (k_dec*t.hip); more: wave
+        /* one round or less of narrow slots: workgroups of entropy, predictor, writer and spare wave (k_dec*q.hip); more: wave
          * pairs. (slots is an upper bound: a partly filled wave per key present; the kernels decide on the real count) */
         const bool one_round = (size_t)slots <= (size_t)4 * dec->n_cu + 2 * 18 * 18 + 8;
         switch (dec->cfg.bit_depth) {
             case 16:
                 a.cap = pair_capacity(alac_decode_16g);
-                if (one_round) pairs(alac_decode_16t, 3u);
+                if (one_round) pairs(alac_decode_16q, 4u);
                 pairs(alac_decode_16);
                 /* as many workgroups as the device holds at once: they share the slots out among themselves */
                 if ((size_t)slots > (size_t)4 * dec->n_cu && a.cap > 4u)
@@ -379,7 +380,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
                 pairs(alac_decode_w32); /* chanBits > 23 only exists at 24 and 32 bits (without their usual shift bytes) */
                 break;
             default: /* 20 and 24 */
-                if (one_round && dec->cfg.num_channels == 2) pairs(alac_decode_24t, 3u);
+                if (one_round && dec->cfg.num_channels == 2) pairs(alac_decode_24q, 4u);
                 pairs(alac_decode_24);
                 if (dec->cfg.bit_depth == 24) pairs(alac_decode_w24);
         }
@@ -489,6 +490,8 @@ void configure(alacgpu_decoder* d, const alacgpu_config* cfg, int bps) {
         const int v = atoi(e);
         if (v == 64 || v == 128 || v == 256) d->il_threads = (uint32_t)v;
     }
+    d->lanes_min = 9;
+    if (const char* e = getenv("ALACGPU_LANES_MIN")) d->lanes_min = (uint32_t)std::max(1, atoi(e)); /* experiments; 17: never */
     d->chunk_bytes = (size_t)192 << 20;
     if (const char* e = getenv("ALACGPU_CHUNK_MB")) {
         const long v = atol(e);

@@ -11,7 +11,7 @@
 #define ALAC_DECODE_DEPTH 16
 #define ALAC_DECODE_GATED 0
 #define ALAC_DECODE_WAVES 2 /* __launch_bounds__: waves per SIMD the register budget must allow */
-#define ALAC_DECODE_SPLIT3 2 /* batches of up to 4 x CUs wave slots belong to alac_decode_16t (k_dec16t.hip) */
+#define ALAC_DECODE_SPLIT3 2 /* batches of up to 4 x CUs wave slots belong to alac_decode_16q (k_dec16q.hip) */
 
 namespace alack {
 
