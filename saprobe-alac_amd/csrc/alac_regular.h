@@ -610,6 +610,8 @@ ALAC_DEV int32_t predict_narrow_core(int32_t (&coef)[NR], const uint32_t (&hb)[N
      * (independent instructions back to back): 2.45 ms vs 3.01 ms on the benchmark batch — with a partner wave on the
      * SIMD filling the gaps, short live ranges matter more than the distance between dependent instructions. */
     int32_t acc = den_half;
+    int32_t accx = 0;                               /* sum coef_j * ex_j (ALAC_TAP_ORDER 1) */
+    const uint32_t ntx = 0u - (topb ^ sgnm);        /* ex_j = (h_j ^ sgnm) + ntx */
     int32_t gos = 1;
 #pragma unroll
     for (int j = NR - 1; j >= 0; --j) {
@@ -631,25 +633,31 @@ ALAC_DEV int32_t predict_narrow_core(int32_t (&coef)[NR], const uint32_t (&hb)[N
         /* Issue order (the build keeps source order, csrc/Makefile): a wave issues in order, an instruction that needs
          * the result of the one right before it waits 8.3 cycles instead of 4.8 (profiles/microbench/valu_more: chains=1),
          * and the predictor wave's own issue rate is what a pair's step takes (round 3: ten instructions more in it cost
-         * 8 %, twenty more in the entropy wave 1 %). So no instruction here uses the result of its predecessor. */
-        const int32_t e = (int32_t)(hb[j] - topb);            /* out[i-1-j] - top; the bias cancels */
+         * 8 %, twenty more in the entropy wave 1 %). So no instruction here uses the result of its predecessor.
+         * EIGHT instructions per tap (round 3; nine before): the difference is formed with the residual's sign already
+         * folded in, ex = +-(out[i-1-j] - top) = (h ^ sgnm) - (top ^ sgnm) in one v_xad_u32 against the step's ntx, so that
+         * the coefficient step sign(del) * sign(e) is sign(ex) itself (no second xad per tap) and the multiply-add chain
+         * sums coef * ex = +-(coef * e): one conditional negation per step (acc, below) puts that right. */
+        const int32_t ex = (int32_t)ALAC_XAD(hb[j], sgnm, ntx);
         const uint32_t ae = ALAC_SAD(topb, hb[j], rnd);       /* |e| + rounding */
-        const int32_t sg = ALAC_SIGN(e);
-        acc = MID ? (int32_t)((uint32_t)acc + (uint32_t)coef[j] * (uint32_t)e)
-                  : ALAC_MAD24(coef[j], e, acc);              /* uses coef[j] before its update */
+        const int32_t delta = ALAC_SIGN(ex);                  /* sign(del) * -sign(top - h_j) */
+        accx = MID ? (int32_t)((uint32_t)accx + (uint32_t)coef[j] * (uint32_t)ex)
+                   : ALAC_MAD24(coef[j], ex, accx);           /* uses coef[j] before its update */
         const uint32_t q = ae >> den_shift;
         int32_t go = ALAC_CLAMP01(rem);                       /* tap j adapts while the budget is not used up */
         if (MID) {
             go &= gos;
             gos = go;
         }
-        /* coefficient step sign(del) * -sign(top - h_j) = sign(del) * sign(e): (sign(e) ^ sgnm) + nsg */
-        const int32_t delta = (int32_t)ALAC_XAD(sg, sgnm, nsg);
         rem = MID ? (int32_t)((uint32_t)rem - q * (na - (uint32_t)j)) : ALAC_MSUB24(rem, q, na - (uint32_t)j);
         const int32_t cj = ALAC_MAD24(delta, go, coef[j]);
         coef[j] = WRAP ? (int32_t)(int16_t)cj : cj;           /* predictor.go:664,675 */
 #endif
     }
+#if ALAC_TAP_ORDER != 0
+    /* den_half + sum coef_j * e_j: the chain's sum with the residual's sign taken out again ((x ^ -1) + 1 = -x) */
+    acc = (int32_t)ALAC_XAD(accx, sgnm, nsg + (uint32_t)den_half);
+#endif
     const int32_t o = del + (int32_t)(topb ^ BIAS) + (acc >> den_shift);
     /* CB_POS: the caller knows chanBits >= 1, so the shift count is <= 31 and sext_cs' guard for 32 is not needed */
     return CB_POS ? ALAC_SEXT_BITS(o, 32u - chan_shift) : sext_cs(o, chan_shift);

@@ -218,19 +218,22 @@ namespace {
 size_t plan_claims_offset() { return (sizeof(Plan) + 255u) & ~(size_t)255u; }
 size_t plan_bytes(size_t waves) { return plan_claims_offset() + waves * 4 * sizeof(uint32_t); }
 
-/* wave pairs of a pair kernel one CU holds at a time (registers and LDS, as the runtime computes it); asked once per kernel */
-template <class K>
-uint32_t pair_capacity(K kernel) {
-    static std::atomic<int> cached{0}; /* one instantiation per kernel; every device here is the same model */
-    int v = cached.load(std::memory_order_relaxed);
-    if (v <= 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, (int)(2 * kWave), 0) != hipSuccess || v <= 0) v = 4;
-        if (const char* e = getenv("ALACGPU_PAIR_CAP")) { /* experiments: fewer pairs per CU than would fit */
-            const int lim = atoi(e);
-            if (lim >= 1 && lim < v) v = lim;
-        }
-        cached.store(v, std::memory_order_relaxed);
+/* wave pairs of a pair kernel one CU holds at a time (registers and LDS, as the runtime computes it); asked once per
+ * kernel: the cache is keyed by the kernel's address (every pair kernel has the same function type, so a function-local
+ * static of a template on that type would be ONE cache for all of them); every device here is the same model */
+uint32_t pair_capacity(void (*kernel)(PairArgs)) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> cache;
+    std::lock_guard<std::mutex> g(mu);
+    for (const auto& e : cache)
+        if (e.first == (const void*)kernel) return (uint32_t)e.second;
+    int v = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kernel, (int)(2 * kWave), 0) != hipSuccess || v <= 0) v = 4;
+    if (const char* e = getenv("ALACGPU_PAIR_CAP")) { /* experiments: fewer pairs per CU than would fit */
+        const int lim = atoi(e);
+        if (lim >= 1 && lim < v) v = lim;
     }
+    cache.emplace_back((const void*)kernel, v);
     return (uint32_t)v;
 }
 

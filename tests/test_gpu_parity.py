@@ -93,6 +93,31 @@ def test_batch_matches_oracle(pkg, oracle, synth, helpers, gpu_decoder_factory, 
                     assert np.array_equal(got[0][i, :nb], b.pcm[i, :nb])
 
 
+@pytest.mark.parametrize("depth,ch,fl,n,profiles", [(16, 2, 4096, 300, "ms"), (16, 1, 700, 300, "ms"), (24, 2, 1024, 300, "ms"),
+                                                      (20, 2, 512, 300, "ms"), (16, 2, 64, 16500, "m"), (24, 2, 48, 16500, "m")])
+def test_two_lane_predictor_waves_match_oracle(pkg, oracle, synth, helpers, gpu_decoder_factory, monkeypatch, depth, ch, fl, n,
+                                               profiles):
+    """The second predictor wave of the four-wave workgroups (k_dec16q / k_dec24q, alac_duo.h: duo_phase_lanes: a packet's
+    taps on two lanes) forced on for EVERY key with orders 3..16 (ALACGPU_LANES_MIN is read when a handle is made; by
+    default only keys with nine taps or more take it): odd and even orders, int16-wrapping and int32 coefficient orders,
+    every denShift, partial frames, escape codes and zero runs beside it (STRESS), and batches of full 64-packet workgroups
+    (16 500 packets: both predictor waves at work, each taking its number of steps from the other's packets too)."""
+    monkeypatch.setenv("ALACGPU_LANES_MIN", "3")
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    with gpu_decoder_factory(cfg) as dec:
+        for prof in [synth.PROFILE_MUSIC] + ([synth.PROFILE_STRESS, synth.PROFILE_QUIET] if "s" in profiles else []):
+            b = synth.gen_batch(cfg, n, profile=prof, threads=8)
+            ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=8)
+            got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
+            helpers.assert_same_decode(cfg, ref, got, bpf, "lanes, profile %d" % prof)
+            if prof != synth.PROFILE_STRESS:
+                assert (got[2] == 0).all()
+                for i in range(0, b.n, max(1, b.n // 500)):
+                    nb = int(b.frames[i]) * bpf
+                    assert np.array_equal(got[0][i, :nb], b.pcm[i, :nb])
+
+
 @pytest.mark.parametrize("depth,ch,fl,kb", [(16, 2, 256, 14), (24, 2, 128, 14), (16, 1, 64, 14), (24, 8, 32, 14),
                                             (20, 3, 50, 14), (32, 2, 64, 14), (16, 2, 256, 0), (16, 2, 8, 255),
                                             (16, 2, 256, 32), (16, 2, 256, 255), (24, 5, 64, 40)])
