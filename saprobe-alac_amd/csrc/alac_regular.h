@@ -177,11 +177,14 @@ ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32
         pos += 16u + 16u * nv;
     }
     /* header and shift block must be wholly inside the packet and the entropy stream must start inside it
-     * (anything else is an error or panic case: decode_wave reports those); with shift bytes, eight bytes of entropy
-     * stream behind them keep the lean decoder's 8-byte windows on the shift values inside the packet
-     * (Bits::window_raw) */
+     * (anything else is an error or panic case: decode_wave reports those); with shift bytes, TEN bytes of entropy
+     * stream behind them keep the lean decoder's fetches on the shift values inside the packet: the 8-byte windows
+     * (Bits::window_raw) and the 12-byte block fetch of the 3-byte writer (Bits::load12), whose last block may hold a
+     * single frame's two shift bytes. (Eight until round 3: a one-frame packet with a nine-byte entropy stream had its
+     * block fetch pulled back by two bytes and came out with the wrong low bytes; found by the GPU suite's 17 000-packet
+     * STRESS batch.) Shorter packets take the whole-packet decoder. */
     const uint64_t ent = (uint64_t)pos + (uint64_t)bs * 8u * (cpe ? 2u : 1u) * ns;
-    if ((ent >> 3) >= size || (bs != 0 && (ent >> 3) + 8u > size)) return KEY_IRREGULAR;
+    if ((ent >> 3) >= size || (bs != 0 && (ent >> 3) + 10u > size)) return KEY_IRREGULAR;
     return nu * 32u + nv + wide;
 }
 

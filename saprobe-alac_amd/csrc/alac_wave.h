@@ -108,7 +108,7 @@ struct BitsT {
         return __builtin_bswap64(raw) << (pos & 7u);
     }
     /* the same without the end handling, for windows that lie wholly inside the packet when the lane is still
-     * decoding (the shift values of a regular packet: classify_regular keeps 8 bytes of entropy stream behind them).
+     * decoding (the shift values of a regular packet: classify_regular keeps 10 bytes of entropy stream behind them).
      * A lane that has run out of frames keeps being asked (lock step): its offset is held inside its packet, what it
      * reads is not used. Needs size >= 8. */
     ALAC_DEV uint64_t window_raw(uint32_t pos) const {

@@ -365,13 +365,16 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
                    (uint32_t*)((uint8_t*)plan + plan_claims_offset()), ppw, dec->n_cu, 0u, dec->lanes_min};
         const uint32_t slots = (uint32_t)max_waves(dec, n, ppw);
         auto pairs = [&](auto kernel, uint32_t roles = 2u) { hipLaunchKernelGGL(kernel, dim3(slots), dim3(roles * kWave), 0, dec->stream, a); };
-        /* one round or less of narrow slots: workgroups of entropy, predictor, writer and spare wave (k_dec*q.hip); more: wave
-         * pairs. (slots is an upper bound: a partly filled wave per key present; the kernels decide on the real count) */
-        const bool one_round = (size_t)slots <= (size_t)4 * dec->n_cu + 2 * 18 * 18 + 8;
+        /* Up to one round of narrow slots: workgroups of entropy, predictor, writer and spare wave (k_dec*q.hip); more: wave
+         * pairs. Which of the two it is, the kernels decide on the device from the plan's count of NARROW REGULAR slots
+         * (k_decode_body.inc: three_waves) — the host only knows an upper bound of all slots, and a batch with many irregular
+         * or wide packets can have few narrow ones — so both kinds are always launched and the one whose turn it is not
+         * exits at once (round 3, found by tools/gpu_fuzz.py: a host-side guess skipped the four-wave launch for batches
+         * the two-wave kernel then left to it). */
         switch (dec->cfg.bit_depth) {
             case 16:
                 a.cap = pair_capacity(alac_decode_16g);
-                if (one_round) pairs(alac_decode_16q, 4u);
+                pairs(alac_decode_16q, 4u);
                 pairs(alac_decode_16);
                 /* as many workgroups as the device holds at once: they share the slots out among themselves */
                 if ((size_t)slots > (size_t)4 * dec->n_cu && a.cap > 4u)
@@ -383,7 +386,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
                 pairs(alac_decode_w32); /* chanBits > 23 only exists at 24 and 32 bits (without their usual shift bytes) */
                 break;
             default: /* 20 and 24 */
-                if (one_round && dec->cfg.num_channels == 2) pairs(alac_decode_24q, 4u);
+                if (dec->cfg.num_channels == 2) pairs(alac_decode_24q, 4u);
                 pairs(alac_decode_24);
                 if (dec->cfg.bit_depth == 24) pairs(alac_decode_w24);
         }

@@ -93,6 +93,26 @@ def test_batch_matches_oracle(pkg, oracle, synth, helpers, gpu_decoder_factory, 
                     assert np.array_equal(got[0][i, :nb], b.pcm[i, :nb])
 
 
+@pytest.mark.parametrize("depth,ch,fl,n,ppw", [(24, 2, 52, 17000, "16"), (16, 2, 41, 99000, ""), (20, 2, 42, 70000, "16"),
+                                                  (24, 2, 227, 16400, "2")])
+def test_large_batches_with_few_narrow_regular_slots(pkg, oracle, synth, helpers, gpu_decoder_factory, monkeypatch, depth, ch,
+                                                     fl, n, ppw):
+    """Large STRESS batches: most wave slots belong to irregular packets and wide keys, so the count of narrow regular
+    slots — what decides on the device between the four-wave kernels and the wave pairs (k_decode_body.inc: three_waves)
+    — is small although the batch is not. Round 3's first version guessed on the HOST, from the upper bound of all slots,
+    whether the four-wave kernel had to be launched: it was not, the wave pairs left the slots to it, and the packets
+    stayed undecoded (found by tools/gpu_fuzz.py; these are its cases)."""
+    if ppw:
+        monkeypatch.setenv("ALACGPU_PPW", ppw)
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    with gpu_decoder_factory(cfg) as dec:
+        b = synth.gen_batch(cfg, n, profile=synth.PROFILE_STRESS, threads=8)
+        ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=8)
+        got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
+        helpers.assert_same_decode(cfg, ref, got, bpf, "STRESS, %d packets" % n)
+
+
 @pytest.mark.parametrize("depth,ch,fl,n,profiles", [(16, 2, 4096, 300, "ms"), (16, 1, 700, 300, "ms"), (24, 2, 1024, 300, "ms"),
                                                       (20, 2, 512, 300, "ms"), (16, 2, 64, 16500, "m"), (24, 2, 48, 16500, "m")])
 def test_two_lane_predictor_waves_match_oracle(pkg, oracle, synth, helpers, gpu_decoder_factory, monkeypatch, depth, ch, fl, n,

@@ -30,6 +30,13 @@ for r in range(rounds):
         os.environ["ALACGPU_PPW"] = str(ppw)
     else:
         os.environ.pop("ALACGPU_PPW", None)
+    lm = rng.choice(["", "", "3", "6"])  # from how many taps on the second predictor wave works (alac_duo.h: duo_phase_lanes; read per handle)
+    if lm:
+        os.environ["ALACGPU_LANES_MIN"] = str(lm)
+    else:
+        os.environ.pop("ALACGPU_LANES_MIN", None)
+    if rng.integers(10) == 0 and fl < 300 and ch <= 2:  # full 64-packet workgroups with one or less per CU: both predictor waves at work
+        n = int(rng.choice([16400, 16500, 17000]))
     kb = int(rng.choice([14, 14, 14, 14, 3, 32, 255, 0]))
     cfg = oracle.make_config(fl, depth, ch, kb=kb)
     bpf = ch * oracle.bytes_per_sample(depth)
@@ -55,7 +62,7 @@ for r in range(rounds):
         assert_same_decode(cfg, ref, (out, fr, st), bpf, "round %d" % r)
     except AssertionError as e:
         bad += 1
-        print("MISMATCH depth %d ch %d fl %d prof %d n %d ppw %r kb %d: %s" % (depth, ch, fl, prof, n, ppw, kb, e), flush=True)
+        print("MISMATCH depth %d ch %d fl %d prof %d n %d ppw %r kb %d lanes_min %r: %s" % (depth, ch, fl, prof, n, ppw, kb, lm, e), flush=True)
     if r % 50 == 49:
         print("round %d" % (r + 1), flush=True)
 print("%d rounds, %d mismatches" % (rounds, bad))

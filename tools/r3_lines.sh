@@ -1,6 +1,6 @@
 #!/bin/bash
-# Bench lines of round 2 beyond the headline (device-resident, 1 GPU): the BASELINE configurations, SURVEY §8(f4)'s
-# formats, the batch-size sweep around the occupancy edge and the 9-key mix. usage: tools/r2_lines.sh <outdir>
+# Bench lines of round 3 beyond the headline (device-resident, 1 GPU): the BASELINE configurations, SURVEY §8(f4)'s
+# formats, the batch-size sweep around the occupancy edge and the 9-key mix. usage: tools/r3_lines.sh <outdir>
 OUT=$1; mkdir -p "$OUT"
 B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-entry"
 $B --packets 4096                                   > $OUT/config_b_4096pkts.json 2>/dev/null
@@ -14,6 +14,11 @@ $B --depth 24 --profile 5                            > $OUT/f4_24bit_stereo_shif
 $B --channels 1                                      > $OUT/f4_16bit_mono.json 2>/dev/null
 $B --channels 6 --packets 21845                      > $OUT/f4_16bit_5_1.json 2>/dev/null
 for p in 32768 66000 70000 81920 98304 114688 131072 196608; do $B --packets $p > $OUT/sweep_$p.json 2>/dev/null; done
+for p in 66000 98304 131072; do $B --depth 24 --packets $p > $OUT/sweep24_$p.json 2>/dev/null; done
+$B --depth 32 --packets 98304                        > $OUT/sweep32_98304.json 2>/dev/null
+for p in 1024 64 1; do $B --packets $p              > $OUT/small_$p.json 2>/dev/null; done
+$B --profile 4                                       > $OUT/no_order12_65536.json 2>/dev/null
+$B --profile 4 --packets 4096                        > $OUT/no_order12_4096.json 2>/dev/null
 $B --profile 6                                       > $OUT/mixed_orders_9keys.json 2>/dev/null
 $B --profile 6 --packets 70000                       > $OUT/mixed_orders_9keys_70000.json 2>/dev/null
 python - "$OUT" <<'PY'
