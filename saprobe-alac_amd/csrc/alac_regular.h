@@ -614,13 +614,14 @@ ALAC_DEV int32_t predict_narrow_core(int32_t (&coef)[NR], const uint32_t (&hb)[N
      * SIMD filling the gaps, short live ranges matter more than the distance between dependent instructions. */
     int32_t acc = den_half;
     int32_t accx = 0;                               /* sum coef_j * ex_j (ALAC_TAP_ORDER 1) */
-    const uint32_t ntx = 0u - (topb ^ sgnm);        /* ex_j = (h_j ^ sgnm) + ntx */
+    uint32_t ntx = 0u - (topb ^ sgnm);              /* ex_j = (h_j ^ sgnm) + ntx */
+    ALAC_OWN_REG(ntx); /* opaque: the compiler would take the sum apart again (xor + sub per tap instead of one v_xad_u32) */
     int32_t gos = 1;
 #pragma unroll
     for (int j = NR - 1; j >= 0; --j) {
         if (GEN && (uint32_t)j >= na) continue; /* scalar branch: taps the order does not have */
 #ifndef ALAC_TAP_ORDER
-#define ALAC_TAP_ORDER 1
+#define ALAC_TAP_ORDER 2
 #endif
 #if ALAC_TAP_ORDER == 0
         const int32_t e = (int32_t)(hb[j] - topb); /* out[i-1-j] - top; the bias cancels */
@@ -632,15 +633,10 @@ ALAC_DEV int32_t predict_narrow_core(int32_t (&coef)[NR], const uint32_t (&hb)[N
         const int32_t cj = ALAC_MAD24(delta, go, coef[j]);
         coef[j] = WRAP ? (int32_t)(int16_t)cj : cj; /* predictor.go:664,675 */
         rem = ALAC_MSUB24(rem, q, na - (uint32_t)j);
-#else
-        /* Issue order (the build keeps source order, csrc/Makefile): a wave issues in order, an instruction that needs
-         * the result of the one right before it waits 8.3 cycles instead of 4.8 (profiles/microbench/valu_more: chains=1),
-         * and the predictor wave's own issue rate is what a pair's step takes (round 3: ten instructions more in it cost
-         * 8 %, twenty more in the entropy wave 1 %). So no instruction here uses the result of its predecessor.
-         * EIGHT instructions per tap (round 3; nine before): the difference is formed with the residual's sign already
-         * folded in, ex = +-(out[i-1-j] - top) = (h ^ sgnm) - (top ^ sgnm) in one v_xad_u32 against the step's ntx, so that
-         * the coefficient step sign(del) * sign(e) is sign(ex) itself (no second xad per tap) and the multiply-add chain
-         * sums coef * ex = +-(coef * e): one conditional negation per step (acc, below) puts that right. */
+#elif ALAC_TAP_ORDER == 1
+        /* the eight-instruction tap (see below) with every instruction an asm statement, in the order of rounds 1-2: the
+         * gated pair kernel (k_dec16g.hip: six pairs per CU) runs 5-8 % faster with this one than with the wait-state-free
+         * order (70 000 packets 3.04 against 3.18 ms, 98 304 3.28 against 3.54), every other kernel slower */
         const int32_t ex = (int32_t)ALAC_XAD(hb[j], sgnm, ntx);
         const uint32_t ae = ALAC_SAD(topb, hb[j], rnd);       /* |e| + rounding */
         const int32_t delta = ALAC_SIGN(ex);                  /* sign(del) * -sign(top - h_j) */
@@ -655,11 +651,43 @@ ALAC_DEV int32_t predict_narrow_core(int32_t (&coef)[NR], const uint32_t (&hb)[N
         rem = MID ? (int32_t)((uint32_t)rem - q * (na - (uint32_t)j)) : ALAC_MSUB24(rem, q, na - (uint32_t)j);
         const int32_t cj = ALAC_MAD24(delta, go, coef[j]);
         coef[j] = WRAP ? (int32_t)(int16_t)cj : cj;           /* predictor.go:664,675 */
+#else
+        /* Issue order (the build keeps source order, csrc/Makefile): a wave issues in order, an instruction that needs
+         * the result of the one right before it waits 8.3 cycles instead of 4.8 (profiles/microbench/valu_more: chains=1),
+         * and the predictor wave's own issue rate is what a pair's step takes (round 3: ten instructions more in it cost
+         * 8 %, twenty more in the entropy wave 1 %). So no instruction here uses the result of its predecessor.
+         * EIGHT instructions per tap (round 3; nine before): the difference is formed with the residual's sign already
+         * folded in, ex = +-(out[i-1-j] - top) = (h ^ sgnm) - (top ^ sgnm) in one v_xad_u32 against the step's ntx, so that
+         * the coefficient step sign(del) * sign(e) is sign(ex) itself (no second xad per tap) and the multiply-add chain
+         * sums coef * ex = +-(coef * e): one conditional negation per step (acc, below) puts that right.
+         * WAIT STATES (round 3). The compiler cannot look into inline asm: it counts an asm statement as no time at all and
+         * assumes its result may need a wait state before anyone reads it, so between an asm statement that writes a
+         * register and the first instruction that reads it there must be an instruction of the compiler's own, or it puts
+         * in an s_nop — and an s_nop costs the predictor wave two thirds of a VALU instruction (measured: 20 more per step
+         * +12.7 %, 20 more v_add +19.6 %). With all eight tap instructions as asm statements the order-12 step carried 20
+         * of them. Hence ex and q are plain C (the compiler's own v_xad_u32 and v_lshrrev_b32) and sit where they part
+         * every asm result from its reader: ae .. q, go and delta .. cj, acc and rem .. the next tap. */
+        const uint32_t ae = ALAC_SAD(topb, hb[j], rnd);       /* |e| + rounding */
+        const int32_t ex = (int32_t)((hb[j] ^ sgnm) + ntx);   /* plain: the compiler's own v_xad_u32 */
+        int32_t go = ALAC_CLAMP01(rem);                       /* tap j adapts while the budget is not used up */
+        if (MID) {
+            go &= gos;
+            gos = go;
+        }
+        const int32_t delta = ALAC_SIGN(ex);                  /* sign(del) * -sign(top - h_j) */
+        const uint32_t q = ae >> den_shift;                   /* plain */
+        accx = MID ? (int32_t)((uint32_t)accx + (uint32_t)coef[j] * (uint32_t)ex)
+                   : ALAC_MAD24(coef[j], ex, accx);           /* uses coef[j] before its update */
+        rem = MID ? (int32_t)((uint32_t)rem - q * (na - (uint32_t)j)) : ALAC_MSUB24(rem, q, na - (uint32_t)j);
+        const int32_t cj = ALAC_MAD24(delta, go, coef[j]);
+        coef[j] = WRAP ? (int32_t)(int16_t)cj : cj;           /* predictor.go:664,675 */
 #endif
     }
-#if ALAC_TAP_ORDER != 0
     /* den_half + sum coef_j * e_j: the chain's sum with the residual's sign taken out again ((x ^ -1) + 1 = -x) */
+#if ALAC_TAP_ORDER == 1
     acc = (int32_t)ALAC_XAD(accx, sgnm, nsg + (uint32_t)den_half);
+#elif ALAC_TAP_ORDER == 2
+    acc = (int32_t)(((uint32_t)accx ^ sgnm) + (nsg + (uint32_t)den_half)); /* plain, like ex */
 #endif
     const int32_t o = del + (int32_t)(topb ^ BIAS) + (acc >> den_shift);
     /* CB_POS: the caller knows chanBits >= 1, so the shift count is <= 31 and sext_cs' guard for 32 is not needed */

@@ -7,6 +7,7 @@
 /* the gated kind (k_decode_body.inc): 26 KB of LDS per pair (64-byte PCM pieces) and at most
  * 168 registers, so that six pairs share a CU */
 #define ALAC_LDS_ROWS 32
+#define ALAC_TAP_ORDER 1 /* alac_regular.h: predict_narrow_core; measured per kernel */
 #include "alac_gpu.h"
 
 #define ALAC_DECODE_KERNEL alac_decode_16g
