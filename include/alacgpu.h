@@ -188,6 +188,11 @@ int alacgpu_kernel_times(alacgpu_decoder* dec, float* ms, size_t max_n, size_t* 
  * s_memtime counter (about 2.1 GHz on MI355X) when the pair began and ended the slot; [3] unused. tests/test_gpu_parity.py checks the spread over
  * the CUs, tools/pair_placement.py prints it. */
 int alacgpu_pair_placement(alacgpu_decoder* dec, uint32_t* tags, size_t max_n, size_t* n_out);
+/* Placement relies on the gfx950 layout of two hardware registers read with s_getreg_b32: HW_ID (SIMD [5:4], CU [11:8],
+ * shader engine [14:13]) and XCC_ID ([3:0]); the index built from them stays below 512 and a CU the census of
+ * alacgpu_create() missed only loses its fixed place in the item order, so a different layout costs speed, not
+ * correctness. Measured and tested on an unpartitioned MI355X (SPX: 256 CUs in 8 XCDs) only; on a partitioned device
+ * (CPX) the CU count per device and the XCD assumptions of the numbering (item i on XCD i mod 8) are untested. */
 
 /* The handle's hipStream_t as an opaque pointer (for callers that enqueue copies). */
 void* alacgpu_stream(alacgpu_decoder* dec);
