@@ -136,6 +136,13 @@ def test_two_lane_predictor_waves_match_oracle(pkg, oracle, synth, helpers, gpu_
                 for i in range(0, b.n, max(1, b.n // 500)):
                     nb = int(b.frames[i]) * bpf
                     assert np.array_equal(got[0][i, :nb], b.pcm[i, :nb])
+            if prof == synth.PROFILE_MUSIC and n <= 1000:
+                # damaged packets beside intact ones: the entropy wave parks a failed lane, the predictor waves keep going
+                rng = np.random.default_rng(7 + depth + ch)
+                blob, offs, sizes = helpers.pack_packets(helpers.mutate_packets(b, rng, 400) + [b.packet(i) for i in range(60)])
+                ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=8)
+                got = _gpu_decode(dec, blob, offs, sizes)
+                helpers.assert_same_decode(cfg, ref, got, bpf, "lanes, damaged packets")
 
 
 @pytest.mark.parametrize("depth,ch,fl,kb", [(16, 2, 256, 14), (24, 2, 128, 14), (16, 1, 64, 14), (24, 8, 32, 14),
