@@ -52,15 +52,12 @@ def pair_kernel(depth, ch, packets):
     """Which of the pair kernels decodes a batch of regular packets (k_decode_body.inc: three_waves / pair_gated decide
     on the device from the number of 64-packet wave slots; 256 CUs assumed here, for the name only)."""
     slots = (packets + 63) // 64
+    name = {16: "16", 20: "24", 24: "24", 32: "32"}[depth]
+    if slots <= 1024:
+        return "alac_decode_%sq (entropy, predictor and writer wave per 64 packets; two predictor waves for long predictors in small batches)" % name
     if depth == 16:
-        if slots <= 1024:
-            return "alac_decode_16q (entropy, predictor and writer wave per 64 packets; two predictor waves for long predictors in small batches)"
         return "alac_decode_16 / alac_decode_16g (wave pairs; the gated twin between the multiples of 4 x CUs slots)"
-    if depth == 32:
-        return "alac_decode_32"
-    if ch == 2 and slots <= (1024 if depth == 20 else 512):
-        return "alac_decode_24q (entropy, predictor and writer wave per 64 packets)"
-    return "alac_decode_24"
+    return "alac_decode_%s (wave pairs)" % name
 
 
 def host_threads():

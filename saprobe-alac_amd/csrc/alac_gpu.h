@@ -2,7 +2,7 @@
  * alac_gpu.h — what the kernel translation units of libalacgpu.so share: the gfx950 forms of the building-block
  * macros of alac_regular.h, the wave policies (GpuWave: LDS stager, bitstream rings, residual queue, DPP reductions;
  * GpuWaveMem: residuals from memory), the launch plan, and the kernels' declarations. The library is built from
- * several translation units (k_sort, k_scan, k_dec16, k_dec16g, k_dec24, k_dec32, k_decw24, k_decw32, k_split, alacgpu)
+ * several translation units (k_sort, k_scan, k_dec16q, k_dec16g, k_dec24q, k_dec32q, k_decw24, k_decw32, k_split, alacgpu)
  * so that the kernels compile in parallel; nothing crosses between them on the device side.
  */
 #ifndef ALAC_GPU_H
@@ -409,8 +409,7 @@ struct PairArgs {
 };
 #define ALAC_DECLARE_DECODE(NAME) __global__ void NAME(PairArgs);
 /* the wave pair over the regular packets, one kernel per class (sample width x channel width) */
-ALAC_DECLARE_DECODE(alac_decode_16) ALAC_DECLARE_DECODE(alac_decode_16g) ALAC_DECLARE_DECODE(alac_decode_16q)
-ALAC_DECLARE_DECODE(alac_decode_24q) ALAC_DECLARE_DECODE(alac_decode_24) ALAC_DECLARE_DECODE(alac_decode_32)
+ALAC_DECLARE_DECODE(alac_decode_16q) ALAC_DECLARE_DECODE(alac_decode_16g) ALAC_DECLARE_DECODE(alac_decode_24q) ALAC_DECLARE_DECODE(alac_decode_32q)
 ALAC_DECLARE_DECODE(alac_decode_w24) ALAC_DECLARE_DECODE(alac_decode_w32)
 #undef ALAC_DECLARE_DECODE
 __global__ void alac_chan_predict(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,

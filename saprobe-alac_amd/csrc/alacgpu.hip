@@ -11,9 +11,11 @@
  *   alac_scatter   one thread per packet: counting-sort scatter into the lane permutation
  *   alac_scan      irregular packets, one wavefront per 64: status, frame count, where each channel starts; with
  *                  more than two channels also every channel's residuals, into the channel's row
- *   alac_decode_{16,24,32}, alac_decode_w{24,32}   regular packets: a PAIR of wavefronts per 64 same-key packets (alac_duo.h):
- *                  entropy wave and predictor / PCM wave, residuals through an LDS queue; PCM staged in LDS, written
- *                  in 64- or 128-B pieces (one kernel and compilation unit per class: sample width x chanBits)
+ *   alac_decode_{16,24,32}q   regular packets: entropy, predictor, writer and spare wave per 64 same-key packets
+ *                  (alac_duo.h), residuals and samples through an LDS queue; PCM staged in LDS, written in 128-B lines
+ *   alac_decode_16g, alac_decode_w{24,32}   the gated twin (16-bit batches between the rounds) and the wide keys: a PAIR
+ *                  of wavefronts (entropy; predictor + PCM) per 64 same-key packets (one kernel and compilation unit per
+ *                  class: sample width x chanBits)
  *   alac_task_classify / alac_plan / alac_scatter / alac_chan_predict   (> 2 channels) one wavefront per 64
  *                  (packet, channel) tasks of the same order: the predictor over the stored residuals, in place
  *   alac_interleave, alac_legacy   PCM of the scanned packets (frame order), whole-packet decoder for the rest
@@ -365,29 +367,27 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
                    (uint32_t*)((uint8_t*)plan + plan_claims_offset()), ppw, dec->n_cu, 0u, dec->lanes_min};
         const uint32_t slots = (uint32_t)max_waves(dec, n, ppw);
         auto pairs = [&](auto kernel, uint32_t roles = 2u) { hipLaunchKernelGGL(kernel, dim3(slots), dim3(roles * kWave), 0, dec->stream, a); };
-        /* Up to one round of narrow slots: workgroups of entropy, predictor, writer and spare wave (k_dec*q.hip); more: wave
-         * pairs. Which of the two it is, the kernels decide on the device from the plan's count of NARROW REGULAR slots
-         * (k_decode_body.inc: three_waves) — the host only knows an upper bound of all slots, and a batch with many irregular
-         * or wide packets can have few narrow ones — so both kinds are always launched and the one whose turn it is not
-         * exits at once (round 3, found by tools/gpu_fuzz.py: a host-side guess skipped the four-wave launch for batches
-         * the two-wave kernel then left to it). */
+        /* One kernel per class of regular packets, each launched over all the wave slots; a kernel leaves the slots of the
+         * other classes alone, and whether a batch is the gated twin's (16-bit, slot counts between the multiples of
+         * 4 x CUs) or the four-wave kernel's is decided on the device from the plan's count of NARROW REGULAR slots
+         * (k_decode_body.inc: pair_gated): the host only knows an upper bound of all slots, so both are always launched
+         * and the one whose turn it is not exits at once. (Round 3, found by tools/gpu_fuzz.py: a host-side guess once
+         * skipped a launch the device then relied on.) */
         switch (dec->cfg.bit_depth) {
             case 16:
                 a.cap = pair_capacity(alac_decode_16g);
                 pairs(alac_decode_16q, 4u);
-                pairs(alac_decode_16);
                 /* as many workgroups as the device holds at once: they share the slots out among themselves */
                 if ((size_t)slots > (size_t)4 * dec->n_cu && a.cap > 4u)
                     hipLaunchKernelGGL(alac_decode_16g, dim3(std::min<uint32_t>(a.cap * dec->n_cu, slots)), dim3(2 * kWave), 0,
                                        dec->stream, a);
                 break;
             case 32:
-                pairs(alac_decode_32);
+                pairs(alac_decode_32q, 4u);
                 pairs(alac_decode_w32); /* chanBits > 23 only exists at 24 and 32 bits (without their usual shift bytes) */
                 break;
             default: /* 20 and 24 */
-                if (dec->cfg.num_channels == 2) pairs(alac_decode_24q, 4u);
-                pairs(alac_decode_24);
+                pairs(alac_decode_24q, 4u);
                 if (dec->cfg.bit_depth == 24) pairs(alac_decode_w24);
         }
     }

@@ -1,13 +1,13 @@
 /*
- * k_dec24q.hip — the four-wave workgroups of k_dec16q.hip (entropy, predictor, writer, spare / second predictor wave) for
- * 20- and 24-bit streams (3-byte samples), mono and stereo, chanBits <= 23: every batch size (these widths have no gated twin: their writers
+ * k_dec32q.hip — the four-wave workgroups of k_dec16q.hip (entropy, predictor, writer, spare / second predictor wave) for
+ * 32-bit streams with their usual shift bytes, chanBits <= 23: every batch size (these widths have no gated twin: their writers
  * need more registers than three waves per SIMD leave).
  */
 #include "alac_gpu.h"
 
-#define ALAC_DECODE_KERNEL alac_decode_24q
+#define ALAC_DECODE_KERNEL alac_decode_32q
 #define ALAC_DECODE_WIDE 0
-#define ALAC_DECODE_DEPTH 24
+#define ALAC_DECODE_DEPTH 32
 #define ALAC_DECODE_GATED 0
 #define ALAC_DECODE_ROLES 4
 #define ALAC_DECODE_WAVES 4 /* __launch_bounds__: waves per SIMD the register budget must allow */
