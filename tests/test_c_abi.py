@@ -81,6 +81,21 @@ def test_go_shim_matches_the_header():
         assert (n_args + 1 if seen else 0) == funcs[name], name
 
 
+def test_go_stream_decoder_stays_on_the_shim():
+    """go/alacgpu_decoder.go (the read-ahead Decoder) is pure Go on top of GPUPacketDecoder: it must not reach into the C
+    ABI itself, and what it uses of the shim must exist there."""
+    src = open(os.path.join(ROOT, "go", "alacgpu_decoder.go")).read()
+    shim = open(os.path.join(ROOT, "go", "alacgpu.go")).read()
+    assert src.startswith("//go:build alacgpu")
+    code = re.sub(r"//[^\n]*", "", src)
+    assert not re.search(r"\bC\.", code) and 'import "C"' not in code
+    for name in ("NewGPUPacketDecoder", "DecodeSamples", "statusErr", "Close", "Format"):
+        assert name in code and re.search(r"func (\([^)]*\) )?%s\(" % name, shim), name
+    # tabs only, no trailing blanks (gofmt's most visible rules; the real check needs a toolchain)
+    for line in src.split("\n"):
+        assert line == line.rstrip() and not line.startswith("    "), line
+
+
 def test_go_files_are_gofmt_clean_when_a_toolchain_exists():
     gofmt = shutil.which("gofmt")
     if not gofmt:

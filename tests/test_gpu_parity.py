@@ -93,6 +93,26 @@ def test_batch_matches_oracle(pkg, oracle, synth, helpers, gpu_decoder_factory, 
                     assert np.array_equal(got[0][i, :nb], b.pcm[i, :nb])
 
 
+@pytest.mark.parametrize("depth,ch,fl,n", [(24, 2, 48, 70000), (32, 2, 40, 99000), (20, 1, 64, 132000), (16, 2, 36, 132000),
+                                              (16, 1, 50, 200000)])
+def test_more_than_one_round_of_four_wave_workgroups(pkg, oracle, synth, helpers, gpu_decoder_factory, depth, ch, fl, n):
+    """Batches of more than 4 x CUs wave slots that are not the gated 16-bit twin's: the four-wave kernels run them in as
+    many rounds as it takes (k_dec16q / k_dec24q / k_dec32q; until the end of round 3 wave pairs did), the spare wave of
+    every workgroup rotating over its CU's SIMDs round after round. PCM, frame counts and status words are the oracle's, and
+    the decoder gives back the source PCM (tests/conformance_test.go:282-291)."""
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    with gpu_decoder_factory(cfg) as dec:
+        b = synth.gen_batch(cfg, n, profile=synth.PROFILE_MUSIC, threads=16)
+        ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=16)
+        got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
+        helpers.assert_same_decode(cfg, ref, got, bpf, "%d packets" % n)
+        assert (got[2] == 0).all()
+        for i in range(0, b.n, 997):
+            nb = int(b.frames[i]) * bpf
+            assert np.array_equal(got[0][i, :nb], b.pcm[i, :nb])
+
+
 @pytest.mark.parametrize("depth,ch,fl,n,ppw", [(24, 2, 52, 17000, "16"), (16, 2, 41, 99000, ""), (20, 2, 42, 70000, "16"),
                                                   (24, 2, 227, 16400, "2")])
 def test_large_batches_with_few_narrow_regular_slots(pkg, oracle, synth, helpers, gpu_decoder_factory, monkeypatch, depth, ch,
