@@ -139,7 +139,8 @@ int alacgpu_decode_packet(alacgpu_decoder* dec, const uint8_t* packet, size_t pa
  * DecodePackets, host buffers. Packet i is blob[offsets[i] .. offsets[i+1]) (dense, e.g. a whole mdat).
  * PCM of packet i is written at out + i*out_stride (out_stride >= frame bytes);
  * frames_out[i] = the packet's sample-frame count (0 on failure), status[i] = status word.
- * A failing packet leaves its output slot unspecified and does not affect others.
+ * A failing packet's slot and the bytes of a slot behind a partial frame read as zero (decoder.go:120,127: DecodePacket
+ * hands back a prefix of a zeroed frame buffer); a failing packet does not affect others.
  * The batch is cut into chunks that are uploaded, decoded and downloaded on three streams at once; the bytes go to
  * the device as they are. Pageable memory is staged through pinned buffers by a few copy threads
  * (ALACGPU_COPY_THREADS); blob / out / frames_out / status that the caller allocated with hipHostMalloc or registered

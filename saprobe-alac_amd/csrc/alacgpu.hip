@@ -715,6 +715,16 @@ int alacgpu_decode_batch(alacgpu_decoder* d, const uint8_t* blob, size_t blob_by
                     status[i] = ALACGPU_ERR_RANGE;
                     frames_out[i] = 0;
                 }
+        /* The kernels leave the bytes behind a partial frame alone, and the device-side PCM slots of a (pooled) handle
+         * hold whatever an earlier batch left there: the caller gets zeros instead, as from DecodePacket's zeroed frame
+         * buffer (decoder.go:120,127). One packet in a hundred has a partial frame. */
+        {
+            const size_t bpf = fb / d->cfg.frame_length; /* bytes per frame */
+            for (size_t i = s.first; i < s.first + s.n; i++) {
+                const size_t have = std::min<size_t>(frames_out[i], d->cfg.frame_length) * bpf;
+                if (have < fb) memset(out + i * out_stride + have, 0, fb - have);
+            }
+        }
         s.busy = false;
         return ALACGPU_E_OK;
     };

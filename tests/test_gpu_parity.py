@@ -332,6 +332,26 @@ def test_24bit_shift_and_8ch_full_frames(pkg, synth, oracle, helpers, gpu_decode
         assert np.array_equal(got[0], b.pcm)
 
 
+def test_bytes_behind_a_partial_frame_read_as_zero_on_a_reused_handle(pkg, synth, oracle, helpers, gpu_decoder_factory):
+    """Host entry: the kernels leave the bytes behind a partial frame alone, and a handle that comes back from the pool
+    (alacgpu_destroy keeps device buffers) still holds an earlier batch's PCM in its staging: the caller must get zeros
+    there, as from DecodePacket's zeroed frame buffer (decoder.go:120,127), not somebody else's samples. (Round 3: found
+    when a large batch ran before test_24bit_shift_and_8ch_full_frames in the same process.)"""
+    cfg = oracle.make_config(512, 24, 2)
+    bpf = 6
+    loud = synth.gen_batch(cfg, 3000, profile=synth.PROFILE_NOISE, threads=8)
+    with gpu_decoder_factory(cfg) as dec:
+        _gpu_decode(dec, loud.blob, loud.offsets, loud.sizes)  # fills the staging with non-zero PCM
+    b = synth.gen_batch(cfg, 3000, profile=synth.PROFILE_STRESS, threads=8)  # a fifth of its packets have partial frames
+    assert (b.frames < 512).sum() > 100
+    with gpu_decoder_factory(cfg) as dec:  # the pooled handle
+        out, fr, st = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
+    ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=8)
+    helpers.assert_same_decode(cfg, ref, (out, fr, st), bpf, "reused handle")
+    for i in range(b.n):
+        assert not out[i, int(fr[i]) * bpf:].any(), "packet %d: bytes behind its %d frames" % (i, fr[i])
+
+
 @pytest.mark.parametrize("depth,ch,fl", [(16, 2, 33), (16, 2, 47), (16, 2, 1000), (16, 1, 4095), (24, 2, 129),
                                          (20, 1, 65), (32, 2, 200), (16, 2, 4097)])
 def test_wave_pair_chunk_tails_and_full_waves(pkg, oracle, synth, helpers, gpu_decoder_factory, monkeypatch, depth, ch, fl):
