@@ -202,6 +202,8 @@ struct alacgpu_decoder {
     size_t frame_bytes;
     hipStream_t stream;                                       /* kernels */
     hipStream_t s_in, s_out;                                  /* host entry: uploads, downloads */
+    hipStream_t s_side;                                       /* launch(): the irregular packets' kernels beside the regular ones' */
+    hipEvent_t ev_fork, ev_join;                              /* s_side leaves `stream` behind the sort and is back before the stop event */
     hipEvent_t ev_start[kTimingSlots], ev_stop[kTimingSlots]; /* ring of per-launch event pairs */
     uint64_t launches;                                       /* since the last timing reset */
     DevBuf scratch_u, scratch_g, plan, cls, perm, sizes_ws;  /* kernel workspace */
@@ -213,6 +215,7 @@ struct alacgpu_decoder {
     DevBuf cu_number;                                        /* PairArgs::cu_number */
     size_t chunk_bytes;                                      /* host entry: target bytes (in + out) per chunk */
     uint32_t lanes_min;                                      /* PairArgs::lanes_min; above 16: no second predictor wave for any key */
+    bool side;                                               /* launch(): irregular packets on s_side (ALACGPU_SIDE=0: all on `stream`) */
 };
 
 namespace {
@@ -352,12 +355,31 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
     hipLaunchKernelGGL(alac_plan, dim3(1), dim3(kWave), 0, dec->stream, plan, ppw);
     hipLaunchKernelGGL(alac_scatter, dim3(nb), dim3(256), 0, dec->stream, (const uint16_t*)dec->cls.p, (uint32_t)n, plan,
                        (uint32_t*)dec->perm.p);
-    /* irregular packets first (usually a handful of waves, or none), then the wave pairs of the regular ones */
-    hipLaunchKernelGGL(alac_scan, dim3((uint32_t)max_waves(dec, n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, blob_bytes,
-                       d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride, d_frames,
-                       d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw, (alac::ChanDesc*)dec->cd.p,
-                       (alac::PktDesc*)dec->pd.p, dec->cfg.num_channels > 2 ? (int32_t*)dec->rows.p : (int32_t*)nullptr,
-                       (uint64_t)row_stride_of(dec->cfg.frame_length));
+    /* Packets of one or two channels: what the irregular ones need (alac_scan, then alac_interleave and alac_legacy: a
+     * handful of waves, or none) depends on the sort alone and touches no wave slot, packet or descriptor of a regular
+     * one, so it runs on a stream of its own BESIDE the workgroups of the regular packets instead of before and behind them
+     * (65 536 stereo packets with 328 escape packets among them: 17 + 22 + 4 us and three kernel boundaries off the
+     * decode). s_side leaves `stream` behind the sort (ev_fork) and is back before the stop event (ev_join): whoever waits
+     * for `stream` waits for it too. With more than two channels the scan IS the decode and everything stays in line. */
+    const bool forked = dec->side && dec->cfg.num_channels <= 2 && alac::lean_config(c);
+    hipStream_t irr = forked ? dec->s_side : dec->stream;
+    if (forked) {
+        HIP_TRY(hipEventRecord(dec->ev_fork, dec->stream));
+        HIP_TRY(hipStreamWaitEvent(dec->s_side, dec->ev_fork, 0));
+    }
+    /* from here on an error must not leave s_side running behind the caller's back */
+    auto rest = [&]() -> int {
+    auto scan = [&]() {
+        hipLaunchKernelGGL(alac_scan, dim3((uint32_t)max_waves(dec, n, ppw)), dim3(kWave), 0, irr, c, d_blob, blob_bytes,
+                           d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride, d_frames,
+                           d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw, (alac::ChanDesc*)dec->cd.p,
+                           (alac::PktDesc*)dec->pd.p, dec->cfg.num_channels > 2 ? (int32_t*)dec->rows.p : (int32_t*)nullptr,
+                           (uint64_t)row_stride_of(dec->cfg.frame_length));
+    };
+    /* in line: irregular packets first. Beside: the regular packets' workgroups go first and fill the device (a scan
+     * wave needs 201 registers and 26 KB of LDS: it finds room where the first of them have finished, long before the
+     * slowest has) */
+    if (!forked) scan();
     if (dec->cfg.num_channels <= 2 && alac::lean_config(c)) {
         /* one kernel per class of regular packets (alac_gpu.h, k_decode_body.inc): each one is launched over all the wave
          * slots and leaves the slots of the other classes alone. gated_cap: how many pairs per CU the gated twin of the
@@ -391,6 +413,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
                 if (dec->cfg.bit_depth == 24) pairs(alac_decode_w24);
         }
     }
+    if (forked) scan();
     HIP_TRY(hipGetLastError());
     if (alac::lean_config(c)) {
         /* irregular packets were only scanned by alac_scan (status, frames, channel descriptors) */
@@ -419,13 +442,24 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
         /* PCM of the split packets (with one or two channels: of the escape-only packets) */
         /* a block takes eight slices of a packet at a time (k_split.hip: kSlices) */
         const uint32_t ib = (uint32_t)std::min<uint64_t>((uint64_t)n * ((bpp + 7u) / 8u), 8192u * (256u / il_threads));
-        hipLaunchKernelGGL(alac_interleave, dim3(ib), dim3(il_threads), 32u * il_threads, dec->stream, c, d_blob, blob_bytes, d_offsets, sz,
+        hipLaunchKernelGGL(alac_interleave, dim3(ib), dim3(il_threads), 32u * il_threads, irr, c, d_blob, blob_bytes, d_offsets, sz,
                            (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::ChanDesc*)dec->cd.p,
                            (const alac::PktDesc*)dec->pd.p, (const int32_t*)dec->rows.p, rs, d_out, (uint64_t)out_stride, bpp);
-        hipLaunchKernelGGL(alac_legacy, dim3((uint32_t)max_waves(dec, n, ppw)), dim3(kWave), 0, dec->stream, c, d_blob, blob_bytes,
+        hipLaunchKernelGGL(alac_legacy, dim3((uint32_t)max_waves(dec, n, ppw)), dim3(kWave), 0, irr, c, d_blob, blob_bytes,
                            d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::PktDesc*)dec->pd.p, d_out,
                            (uint64_t)out_stride, d_frames, d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw);
         HIP_TRY(hipGetLastError());
+    }
+    if (forked) {
+        HIP_TRY(hipEventRecord(dec->ev_join, dec->s_side));
+        HIP_TRY(hipStreamWaitEvent(dec->stream, dec->ev_join, 0));
+    }
+    return ALACGPU_E_OK;
+    };
+    rc = rest();
+    if (rc != ALACGPU_E_OK) {
+        if (forked) (void)hipStreamSynchronize(dec->s_side);
+        return rc;
     }
     HIP_TRY(hipEventRecord(dec->ev_stop[slot], dec->stream));
     dec->launches++;
@@ -460,6 +494,7 @@ void really_destroy(alacgpu_decoder* d) {
     if (d->stream) (void)hipStreamSynchronize(d->stream);
     if (d->s_in) (void)hipStreamSynchronize(d->s_in);
     if (d->s_out) (void)hipStreamSynchronize(d->s_out);
+    if (d->s_side) (void)hipStreamSynchronize(d->s_side);
     delete d->pool;
     DevBuf* bufs[] = {&d->cu_number, &d->scratch_u, &d->scratch_g, &d->plan, &d->cls, &d->perm, &d->sizes_ws, &d->cd, &d->pd,
                       &d->plan2, &d->keys2, &d->perm2, &d->rows};
@@ -481,6 +516,9 @@ void really_destroy(alacgpu_decoder* d) {
     if (d->stream) (void)hipStreamDestroy(d->stream);
     if (d->s_in) (void)hipStreamDestroy(d->s_in);
     if (d->s_out) (void)hipStreamDestroy(d->s_out);
+    if (d->s_side) (void)hipStreamDestroy(d->s_side);
+    if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
+    if (d->ev_join) (void)hipEventDestroy(d->ev_join);
     delete d;
 }
 
@@ -498,6 +536,8 @@ void configure(alacgpu_decoder* d, const alacgpu_config* cfg, int bps) {
     }
     d->lanes_min = 9;
     if (const char* e = getenv("ALACGPU_LANES_MIN")) d->lanes_min = (uint32_t)std::max(1, atoi(e)); /* experiments; 17: never */
+    d->side = true;
+    if (const char* e = getenv("ALACGPU_SIDE")) d->side = atoi(e) != 0; /* A/B in one process (tools/ab_bench.py) */
     d->chunk_bytes = (size_t)192 << 20;
     if (const char* e = getenv("ALACGPU_CHUNK_MB")) {
         const long v = atol(e);
@@ -552,11 +592,15 @@ int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out)
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
         d->n_cu = cus > 0 ? (uint32_t)cus : 256u;
     }
-    d->stream = d->s_in = d->s_out = nullptr;
+    d->stream = d->s_in = d->s_out = d->s_side = nullptr;
+    d->ev_fork = d->ev_join = nullptr;
     for (uint32_t i = 0; i < kTimingSlots; i++) d->ev_start[i] = d->ev_stop[i] = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_in, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_out, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming);
     for (uint32_t i = 0; i < kTimingSlots && e == hipSuccess; i++) {
         e = hipEventCreate(&d->ev_start[i]);
         if (e == hipSuccess) e = hipEventCreate(&d->ev_stop[i]);
@@ -584,7 +628,7 @@ void alacgpu_destroy(alacgpu_decoder* d) {
     (void)hipSetDevice(d->device);
     /* nothing of this handle's last call may still be running when its belongings go to the next owner */
     bool ok = hipStreamSynchronize(d->stream) == hipSuccess && hipStreamSynchronize(d->s_in) == hipSuccess &&
-              hipStreamSynchronize(d->s_out) == hipSuccess;
+              hipStreamSynchronize(d->s_out) == hipSuccess && hipStreamSynchronize(d->s_side) == hipSuccess;
     if (ok) {
         for (int k = 0; k < kSlots; k++) d->slots[k].busy = false;
         DevBuf* bufs[] = {&d->scratch_u, &d->scratch_g, &d->plan, &d->cls, &d->perm, &d->sizes_ws, &d->cd, &d->pd,
@@ -822,6 +866,7 @@ int alacgpu_decode_batch(alacgpu_decoder* d, const uint8_t* blob, size_t blob_by
          * no slot may carry a chunk of this call into the next one */
         (void)hipStreamSynchronize(d->s_in);
         (void)hipStreamSynchronize(d->stream);
+        (void)hipStreamSynchronize(d->s_side);
         (void)hipStreamSynchronize(d->s_out);
         for (int k = 0; k < kSlots; k++) d->slots[k].busy = false;
         return rc;

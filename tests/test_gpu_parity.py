@@ -606,3 +606,51 @@ def test_gated_pairs_on_full_length_packets(pkg, synth, oracle, helpers, gpu_dec
     if 4 * n_cu < len(tags) <= 6 * n_cu:
         owned = tags[tags != 0]
         assert len(owned) >= len(tags) - 24 and (owned >> 31).all()
+
+
+@pytest.mark.parametrize("side", ["1", "0"])
+def test_irregular_packets_beside_the_regular_ones_back_to_back(pkg, synth, oracle, helpers, gpu_decoder_factory, monkeypatch,
+                                                                side):
+    """launch() forks the irregular packets' kernels (alac_scan, alac_interleave, alac_legacy) onto a stream of their own
+    beside the regular packets' workgroups and joins before the stop event (ALACGPU_SIDE=0: all in line, the order of
+    rounds 1-3). Two different batches with escape, damaged and order-17+ packets among regular ones go through ONE handle's
+    device entry six times back to back without a host synchronisation in between (each launch clears and re-sorts the
+    plan the previous launch's side kernels were still reading if the join did not hold); every result must be the
+    oracle's (decoder.go:142-203: element walk, escape elements; status words of the damaged packets)."""
+    import torch
+    monkeypatch.setenv("ALACGPU_SIDE", side)
+    fl, n = 352, 3000
+    cfg = oracle.make_config(fl, 16, 2)
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda:0")
+    batches = []
+    for k, prof in enumerate((synth.PROFILE_STRESS, synth.PROFILE_MUSIC)):
+        b = synth.gen_batch(cfg, n, profile=prof, base_seed=900 + k, threads=8)
+        packets = [b.packet(i) for i in range(n)]
+        noise = synth.gen_batch(cfg, n // 8, profile=synth.PROFILE_NOISE, base_seed=77 + k, threads=8)
+        for j in range(n // 8):
+            packets[j * 8 + 5] = noise.packet(j)  # escape elements: scan + interleave
+        for j, p in enumerate(helpers.mutate_packets(b, rng, n // 16)):
+            packets[j * 16 + 2] = p
+        blob, offs, sizes = helpers.pack_packets(packets)
+        ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=8)
+        stride = fl * 4
+        t = dict(blob=torch.from_numpy(np.ascontiguousarray(blob)).to(dev), off=torch.from_numpy(offs.astype(np.int64)).to(dev),
+                 sz=torch.from_numpy(sizes.astype(np.int32)).to(dev), ref=ref, stride=stride,
+                 outs=[(torch.zeros((n, stride), dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
+                        torch.full((n,), -1, dtype=torch.int32, device=dev)) for _ in range(3)])
+        batches.append(t)
+    torch.cuda.synchronize()
+    with gpu_decoder_factory(cfg) as dec:
+        for r in range(3):
+            for t in batches:
+                o, f, s = t["outs"][r]
+                dec.decode_batch_device(t["blob"].data_ptr(), t["blob"].numel(), t["off"].data_ptr(), t["sz"].data_ptr(), n,
+                                        o.data_ptr(), t["stride"], f.data_ptr(), s.data_ptr(), sync=False)
+        dec.synchronize()
+    for k, t in enumerate(batches):
+        assert len(np.unique(t["ref"][2])) > 2  # damaged packets among them
+        for r in range(3):
+            o, f, s = t["outs"][r]
+            got = (o.cpu().numpy(), f.cpu().numpy().astype(np.uint32), s.cpu().numpy())
+            helpers.assert_same_decode(cfg, t["ref"], got, 4, "batch %d round %d side %s" % (k, r, side))
