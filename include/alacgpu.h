@@ -160,7 +160,10 @@ int alacgpu_decode_batch(alacgpu_decoder* dec, const uint8_t* blob, size_t blob_
  * [0, blob_bytes) gets status ALACGPU_ERR_RANGE and is not read. Asynchronous on the handle's stream
  * (alacgpu_stream()) unless sync != 0: the inputs must be complete, or ordered on that stream, before the call, and
  * the outputs are complete after alacgpu_synchronize() (the stream is non-blocking: it does not order against the
- * legacy default stream or torch's current stream by itself).
+ * legacy default stream or torch's current stream by itself). Some of a decode's kernels (those of the irregular
+ * packets of 1-2 channel streams) run on a second stream inside the handle; it leaves the handle's stream after the
+ * sort and joins it again before the decode's last event, so work a caller orders behind the handle's stream (an
+ * event, a copy enqueued on alacgpu_stream()) is ordered behind those kernels as well.
  */
 int alacgpu_decode_batch_device(alacgpu_decoder* dec, const uint8_t* d_blob, size_t blob_bytes,
                                 const uint64_t* d_offsets, const uint32_t* d_sizes,

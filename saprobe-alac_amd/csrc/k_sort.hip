@@ -61,18 +61,13 @@ __global__ void __launch_bounds__(kWave) alac_plan(Plan* plan, uint32_t ppw) {
     __syncthreads();
     constexpr uint32_t R = (kKeys + kWave - 1) / kWave;
     const uint32_t q0 = threadIdx.x * R; /* dispatch position q holds key kKeys - 1 - q */
-    /* wave slots of a key: packets per wave is a power of two unless ALACGPU_PPW says otherwise, and two divisions per
-     * key were most of this kernel's 13 us */
-    const bool pow2 = (ppw & (ppw - 1u)) == 0u;
-    const uint32_t sh = 31u - (uint32_t)__builtin_clz(ppw);
-    auto slots_of = [&](uint32_t c) { return pow2 ? (c + ppw - 1u) >> sh : (c + ppw - 1u) / ppw; };
     uint32_t p = 0, w = 0, z = 0, wi = 0, ww = 0;
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t q = q0 + r;
         if (q >= kKeys) break;
         const uint32_t key = kKeys - 1u - q;
         const uint32_t c = cnt[key];
-        const uint32_t cw = slots_of(c);
+        const uint32_t cw = (c + ppw - 1) / ppw;
         p += c;
         w += cw;
         z += c ? 1u : 0u;
@@ -107,7 +102,7 @@ __global__ void __launch_bounds__(kWave) alac_plan(Plan* plan, uint32_t ppw) {
             plan->list_wave0[ez] = ew;
             ++ez;
             ep += c;
-            ew += slots_of(c);
+            ew += (c + ppw - 1) / ppw;
         }
     }
     if (threadIdx.x == kWave - 1u) {
