@@ -215,7 +215,7 @@ struct alacgpu_decoder {
     DevBuf cu_number;                                        /* PairArgs::cu_number */
     size_t chunk_bytes;                                      /* host entry: target bytes (in + out) per chunk */
     uint32_t lanes_min;                                      /* PairArgs::lanes_min; above 16: no second predictor wave for any key */
-    bool side;                                               /* launch(): irregular packets on s_side (ALACGPU_SIDE=0: all on `stream`) */
+    int side;                                                /* launch(): irregular packets on s_side (ALACGPU_SIDE: 0 never, 1 up to 6 x CUs wave slots, 2 always) */
 };
 
 namespace {
@@ -360,8 +360,14 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
      * one, so it runs on a stream of its own BESIDE the workgroups of the regular packets instead of before and behind them
      * (65 536 stereo packets with 328 escape packets among them: 17 + 22 + 4 us and three kernel boundaries off the
      * decode). s_side leaves `stream` behind the sort (ev_fork) and is back before the stop event (ev_join): whoever waits
-     * for `stream` waits for it too. With more than two channels the scan IS the decode and everything stays in line. */
-    const bool forked = dec->side && dec->cfg.num_channels <= 2 && alac::lean_config(c);
+     * for `stream` waits for it too. With more than two channels the scan IS the decode and everything stays in line.
+     * Only while the regular packets' workgroups (nearly) fit the device at once, up to 6 x CUs full wave slots (measured: 4 096,
+     * 32 768, 65 536, 70 000 and 98 304 packets, 16- and 24-bit: 0.8-2.2 % faster). Beyond that workgroups of later rounds
+     * wait for room, and alac_scan and alac_legacy put one workgroup per wave slot of the batch into the same wait, 26 KB of
+     * LDS and 201 registers each though nearly all of them exit at once: 131 072 packets 4.01 -> 4.49 ms, 24-bit 4.76 -> 5.90,
+     * 196 608 packets 5.78 -> 6.29 (profiles/r03_final/ab_side_stream_*.txt). Those batches keep the order of rounds 1-3. */
+    const bool forked = dec->cfg.num_channels <= 2 && alac::lean_config(c) &&
+                        (dec->side >= 2 || (dec->side == 1 && (n + ppw - 1) / ppw <= (size_t)6 * dec->n_cu));
     hipStream_t irr = forked ? dec->s_side : dec->stream;
     if (forked) {
         HIP_TRY(hipEventRecord(dec->ev_fork, dec->stream));
@@ -536,8 +542,8 @@ void configure(alacgpu_decoder* d, const alacgpu_config* cfg, int bps) {
     }
     d->lanes_min = 9;
     if (const char* e = getenv("ALACGPU_LANES_MIN")) d->lanes_min = (uint32_t)std::max(1, atoi(e)); /* experiments; 17: never */
-    d->side = true;
-    if (const char* e = getenv("ALACGPU_SIDE")) d->side = atoi(e) != 0; /* A/B in one process (tools/ab_bench.py) */
+    d->side = 1;
+    if (const char* e = getenv("ALACGPU_SIDE")) d->side = atoi(e); /* experiments, tests */
     d->chunk_bytes = (size_t)192 << 20;
     if (const char* e = getenv("ALACGPU_CHUNK_MB")) {
         const long v = atol(e);

@@ -608,12 +608,12 @@ def test_gated_pairs_on_full_length_packets(pkg, synth, oracle, helpers, gpu_dec
         assert len(owned) >= len(tags) - 24 and (owned >> 31).all()
 
 
-@pytest.mark.parametrize("side", ["1", "0"])
+@pytest.mark.parametrize("side", ["2", "1", "0"])
 def test_irregular_packets_beside_the_regular_ones_back_to_back(pkg, synth, oracle, helpers, gpu_decoder_factory, monkeypatch,
                                                                 side):
     """launch() forks the irregular packets' kernels (alac_scan, alac_interleave, alac_legacy) onto a stream of their own
     beside the regular packets' workgroups and joins before the stop event (ALACGPU_SIDE=0: all in line, the order of
-    rounds 1-3). Two different batches with escape, damaged and order-17+ packets among regular ones go through ONE handle's
+    rounds 1-3; 1: batches of up to 6 x CUs wave slots; 2: always). Two different batches with escape, damaged and order-17+ packets among regular ones go through ONE handle's
     device entry six times back to back without a host synchronisation in between (each launch clears and re-sorts the
     plan the previous launch's side kernels were still reading if the join did not hold); every result must be the
     oracle's (decoder.go:142-203: element walk, escape elements; status words of the damaged packets)."""
