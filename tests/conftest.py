@@ -135,6 +135,31 @@ def mutate_packets(batch, rng, n_out):
     return pk
 
 
+def loud_packets(synth, cfg, n, seed=1, pb_factor=7, order=0):
+    """Packets whose residuals keep the Golomb mean at the top of its range: compressed elements (never the escape
+    form) whose folded residuals n = 2|r| (- 1) sit in 56 000..65 535 sample after sample, with pbFactor 7 — the largest
+    effective pb = PB * 7 / 4 a cookie byte PB can give (decoder.go:296-299) — so that mean approaches 512 * 65 535 and
+    pb * mean (golomb.go:215) its largest product; one sample in sixteen is the most negative value of the channel
+    (n = 65 535 exactly, or beyond it and into the clamp of golomb.go:216-218 where the channel is wider than 16 bits).
+    order 0: the samples ARE the residuals (predictor.go:53-56). -> list of (packet bytes, expected PCM bytes)."""
+    rng = np.random.default_rng(seed)
+    depth, ch, fl = cfg.bit_depth, cfg.num_channels, cfg.frame_length
+    bs = {16: 0, 20: 0, 24: 1, 32: 2}[depth]
+    ne = synth.num_elements(ch)
+    out = []
+    for _ in range(n):
+        mag = rng.integers(28000, 32768, size=(fl, ch))
+        sgn = rng.choice([-1, 1], size=(fl, ch))
+        hi = mag * sgn
+        hi[rng.integers(0, 16, size=(fl, ch)) == 0] = -32768 if depth == 16 else -(1 << (depth - 8 * bs - 1))
+        pcm = (hi.astype(np.int64) << (8 * bs)) | rng.integers(0, 1 << (8 * bs), size=(fl, ch)) if bs else hi
+        pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+        elems = [synth.default_elem(order=order, pb_factor=pb_factor, mix_res=0, mix_bits=0, bytes_shifted=bs, never_escape=1)
+                 for _ in range(ne)]
+        out.append((synth.encode_packet(cfg, elems, pcm), synth.pack_pcm(cfg, pcm)))
+    return out
+
+
 def assert_same_decode(cfg, ref, got, bpf, what=""):
     """(out, frames, status) triples must agree: status, frame count, and PCM bytes of the frames."""
     o1, f1, s1 = ref
@@ -157,6 +182,7 @@ def helpers():
     H.pack_dense = staticmethod(pack_dense)
     H.mutate_packets = staticmethod(mutate_packets)
     H.assert_same_decode = staticmethod(assert_same_decode)
+    H.loud_packets = staticmethod(loud_packets)
     return H
 
 

@@ -1,4 +1,5 @@
-"""Assembles the hand-built known-answer packets K5..K13 into tests/golden/kat2.json and K14..K19 into kat3.json.
+"""Assembles the hand-built known-answer packets K5..K13 into tests/golden/kat2.json, K14..K19 into kat3.json and K20..K22
+(cookie bytes PB / MB other than 40 / 10) into kat4.json.
 
 This script only PACKS BITS: every field below was chosen by hand, every expected PCM byte string was worked out on
 paper from the reference source (tests/golden/kat_derivation.md holds the derivations, step by step, with the reference
@@ -6,7 +7,7 @@ lines they follow) and is typed in here as a constant. Nothing in this file deco
 goref, kernel) was used to produce the expectations. tests/test_oracle.py, tests/test_goref.py and
 tests/test_gpu_parity.py then require the C oracle, the Python transliteration and the HIP kernels to reproduce them.
 
-    python tests/golden/kat_build.py        # rewrites kat2.json and kat3.json
+    python tests/golden/kat_build.py        # rewrites kat2.json, kat3.json and kat4.json
 """
 import json
 import os
@@ -299,6 +300,74 @@ def build3():
     return kats
 
 
+def build4():
+    """K20..K22 (round 4): cookie bytes PB and MB other than 40 / 10 (config.go:72-73), the mean trajectories worked on
+    paper from golomb.go:172-246 with pb = PB * pbFactor / 4 (decoder.go:296-299). Derivations: kat_derivation.md, third
+    part. All three are 16- / 20-bit SCEs with numActive 0 (the samples are the residuals, predictor.go:53-60) and
+    FrameLength 40, so that the GPU library sorts them under a regular key (alac_regular.h: classify_regular)."""
+    kats = []
+
+    # ---- K20: PB 20, pbFactor 6 -> pb 30; MB 0: first mean 0, a zero run at once, k = 1 -> 2, an escape code, then
+    #      the fixed point mean = 3584 = 512 * 7 with n = 7 for ever ---------------------------------------------------
+    bw = BitWriter()
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 0, 6, [])
+    bw.raw("1110")                           # s0: k = 1, n = 3 -> -2; mean 90 -> zero run, k32 = 2, mz = 3
+    bw.raw("0 10")                           # run of 1 (s1 = 0)
+    bw.raw("111111110")                      # s2: zmode: n = 8, nd = 9 -> -5; mean 270
+    bw.raw("11111110")                       # s3: n = 7 -> -4; mean 465
+    bw.raw("111111110")                      # s4: n = 8 -> +4; mean 678
+    bw.raw("110 11")                         # s5: k = 2: pre 2, v 3 -> n = 8 -> +4; mean 879
+    bw.raw("10 0")                           # s6: k = 2: pre 1, v < 2 -> n = 3 -> -2; mean 918
+    bw.raw("0 10")                           # s7: k = 2: pre 0, v 2 -> n = 1 -> -1; mean 895
+    bw.raw("0 0")                            # s8: n = 0; mean 843
+    bw.raw("111111111").put(93, 16)          # s9: escape code, n = 93 -> -47; mean 3584
+    for _ in range(30):
+        bw.raw("10 00")                      # s10..s39: k = 3, m = 7: pre 1, v < 2 -> n = 7 -> -4; mean stays 3584
+    bw.put(7, 3)
+    kats.append({"name": "K20 PB 20 (pb 30), MB 0", "frame_length": 40, "bit_depth": 16, "num_channels": 1, "pb": 20, "mb": 0,
+                 "packet": bw.hex(), "pcm": le([-2, 0, -5, -4, 4, 4, -2, -1, 0, -47] + [-4] * 30, 2)})
+
+    # ---- K21: PB 73, pbFactor 7 -> pb 127, the largest the lean Golomb step of the kernels takes; MB 255; the mean climbs
+    #      to 21 005 824 = 512 * 41 027 and stays there -----------------------------------------------------------------
+    bw = BitWriter()
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 0, 7, [])
+    bw.raw("111111111").put(0xFFFF, 16)      # s0: k = 1, escape code, n = 65535 -> -32768; mean 8 323 137
+    bw.raw("11111110").put(8191, 13)         # s1: k = 13: pre 7, v 8191 -> n = 65527 -> -32764; mean 14 580 538
+    bw.raw("1110").put(16383, 14)            # s2: k = 14: pre 3, v 16383 -> n = 65531 -> -32766; mean 19 286 319
+    bw.raw("1110").put(2060, 14)             # s3: pre 3, v 2060 -> n = 51208 -> +25604; mean 21 005 824
+    for _ in range(36):
+        bw.raw("110").put(8262, 14)          # s4..s39: pre 2, v 8262 -> n = 41027 -> -20514; mean stays
+    bw.put(7, 3)
+    kats.append({"name": "K21 PB 73 (pb 127), MB 255", "frame_length": 40, "bit_depth": 16, "num_channels": 1, "pb": 73,
+                 "mb": 255, "packet": bw.hex(), "pcm": le([-32768, -32764, -32766, 25604] + [-20514] * 36, 2)})
+
+    # ---- K22: PB 255, pbFactor 7 -> pb 446: pb * mean wraps in uint32 (golomb.go:215); MB 1; 20-bit, so that an escape code
+    #      can carry n = 65536 > 0xffff and the clamp (golomb.go:216-218) brings the mean back; then down into a zero run ---
+    bw = BitWriter()
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 0, 7, [])
+    bw.raw("111111111").put(0xFFFF, 20)      # s0: k = 1, escape code, n = 65535 -> -32768; mean 29 228 611
+    bw.raw("0").put(2, 14)                   # s1: k = 14: pre 0, v 2 -> n = 1 -> -1; 446 * mean wraps; mean 28 934 021
+    bw.raw("10").put(16383, 14)              # s2: pre 1, v 16383 -> n = 32765 -> -16383; wraps; mean 43 508 791
+    bw.raw("0").put(0, 13)                   # s3: pre 0, v < 2 -> n = 0; wraps; mean 39 162 988
+    bw.raw("111111111").put(0x10000, 20)     # s4: escape code, n = 65536 -> +32768; mean clamped to 65535
+    bw.raw("0").put(0, 6)                    # s5: k = 7: n = 0; mean 8448
+    bw.raw("0").put(0, 3)                    # s6: k = 4: n = 0; mean 1089
+    bw.raw("0 0")                            # s7: k = 2: n = 0; mean 141
+    bw.raw("0")                              # s8: k = 1: n = 0; mean 19 -> zero run, k32 = 3, mz = 7
+    bw.raw("11110 100")                      # run of 4 * 7 + 4 - 1 = 31: s9..s39
+    bw.put(7, 3)
+    vals = [-32768, -1, -16383, 0, 32768, 0, 0, 0, 0] + [0] * 31
+    kats.append({"name": "K22 PB 255 (pb 446: uint32 wrap), MB 1, 20-bit", "frame_length": 40, "bit_depth": 20,
+                 "num_channels": 1, "pb": 255, "mb": 1, "packet": bw.hex(), "pcm": le([v << 4 for v in vals], 3)})
+    return kats
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     out = {"_source": "hand-built packets; expected PCM derived on paper from the reference source in "
@@ -310,6 +379,12 @@ def main():
     print("wrote", path, len(out["vectors"]), "vectors")
     out["vectors"] = build3()
     path = os.path.join(here, "kat3.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path, len(out["vectors"]), "vectors")
+    out["config_common"] = {"kb": 14, "max_run": 255}  # PB and MB per vector
+    out["vectors"] = build4()
+    path = os.path.join(here, "kat4.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path, len(out["vectors"]), "vectors")

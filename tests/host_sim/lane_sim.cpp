@@ -16,7 +16,12 @@
 
 #define ALAC_DEV inline
 /* as narrow as the GPU's v_mul_i32_i24: a use on operands that do not fit 24 bits must show up here too */
-#define ALAC_MUL24(a, b) ((int32_t)((uint32_t)(((int32_t)((uint32_t)(a) << 8)) >> 8) * (uint32_t)(((int32_t)((uint32_t)(b) << 8)) >> 8)))
+#define ALAC_SX24(x) (((int32_t)((uint32_t)(x) << 8)) >> 8)
+#define ALAC_MUL24(a, b) ((int32_t)((uint32_t)ALAC_SX24(a) * (uint32_t)ALAC_SX24(b)))
+/* ... and so are the multiply-adds of alac_regular.h (v_mad_i32_i24, v_mul_u32_u24: operands cut to 24 bits) */
+#define ALAC_MAD24(a, b, c) ((int32_t)((uint32_t)ALAC_SX24(a) * (uint32_t)ALAC_SX24(b) + (uint32_t)(c)))
+#define ALAC_MSUB24(acc, a, c) ((int32_t)((uint32_t)(acc) - (uint32_t)ALAC_SX24(a) * (uint32_t)ALAC_SX24(c)))
+#define ALAC_MULU24(a, b) (((uint32_t)(a) & 0xffffffu) * ((uint32_t)(b) & 0xffffffu))
 #include "../../saprobe-alac_amd/csrc/alac_wave.h"
 #include "../../saprobe-alac_amd/csrc/alac_regular.h"
 #include "../../saprobe-alac_amd/csrc/alac_duo.h"

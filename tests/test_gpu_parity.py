@@ -35,12 +35,14 @@ def test_known_answer_packets_on_gpu(pkg):
 
 
 def test_hand_derived_predictor_and_matrix_packets_on_gpu(pkg):
-    """K5..K13 and K14..K19 (tests/golden/kat_derivation.md) through DecodePacket on the GPU."""
+    """K5..K13, K14..K19 and K20..K22 (other cookie bytes: PB 20 / 73 / 255, MB 0 / 255 / 1; tests/golden/kat_derivation.md)
+    through DecodePacket on the GPU."""
     k = json.load(open(os.path.join(HERE, "golden", "kat2.json")))
     c = k["config_common"]
-    for v in k["vectors"] + json.load(open(os.path.join(HERE, "golden", "kat3.json")))["vectors"]:
+    more = [json.load(open(os.path.join(HERE, "golden", n)))["vectors"] for n in ("kat3.json", "kat4.json")]
+    for v in k["vectors"] + more[0] + more[1]:
         cfg = pkg.PacketConfig(FrameLength=v["frame_length"], BitDepth=v["bit_depth"], NumChannels=v["num_channels"],
-                               PB=c["pb"], MB=v["mb"], KB=c["kb"], MaxRun=c["max_run"])
+                               PB=v.get("pb", c["pb"]), MB=v["mb"], KB=c["kb"], MaxRun=c["max_run"])
         with pkg.NewPacketDecoder(cfg) as dec:
             pcm = dec.DecodePacket(bytes.fromhex(v["packet"]))
             assert pcm.hex().upper() == v["pcm"].upper(), v["name"]
@@ -188,6 +190,78 @@ def test_corrupt_packets_match_oracle_and_do_not_poison_the_batch(pkg, oracle, s
         got = _gpu_decode(dec, blob, offs, sizes)
         helpers.assert_same_decode(cfg, ref, got, bpf, "fuzz")
         assert (ref[2] != 0).sum() > 100 and (ref[2] == 0).sum() > 100
+
+
+@pytest.mark.parametrize("pb", [0, 1, 20, 39, 41, 73, 74, 127, 255])
+def test_other_cookie_bytes_pb_and_mb_match_oracle(pkg, oracle, synth, helpers, gpu_decoder_factory, pb):
+    """PB and MB are bytes of an untrusted file's magic cookie (config.go:72-73); effective pb = PB * pbFactor / 4
+    (decoder.go:296-299), first mean MB (golomb.go:157). PB <= 73 takes the lean Golomb step (alac_regular.h: lean_config:
+    pb <= 127, mean < 2^25 + 512, pb * mean does not wrap), larger ones the whole-packet decoder with the reference's uint32
+    arithmetic (golomb.go:215): both sides of that edge and the extremes, MB 0 / 1 / 10 / 255, on MUSIC / QUIET / NOISE /
+    STRESS (pbFactor 0..7) streams of 1, 2 and 6 channels, damaged packets beside intact ones, and `loud` packets that hold
+    the mean at the top of its range with pbFactor 7 (conftest.loud_packets)."""
+    rng = np.random.default_rng(1000 + pb)
+    for mb in (0, 1, 10, 255):
+        for depth, ch, fl in ((16, 2, 300), (16, 1, 200), (24, 2, 128), (16, 6, 64), (20, 2, 96), (32, 1, 80)):
+            cfg = oracle.make_config(fl, depth, ch, pb=pb, mb=mb)
+            bpf = ch * oracle.bytes_per_sample(depth)
+            with gpu_decoder_factory(cfg) as dec:
+                for prof in (synth.PROFILE_MUSIC, synth.PROFILE_QUIET, synth.PROFILE_STRESS, synth.PROFILE_NOISE):
+                    b = synth.gen_batch(cfg, 150, profile=prof, base_seed=pb * 1000 + mb, threads=8)
+                    ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=8)
+                    got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
+                    helpers.assert_same_decode(cfg, ref, got, bpf, "pb %d mb %d %d-bit %d-ch profile %d" % (pb, mb, depth, ch, prof))
+                    if prof != synth.PROFILE_STRESS:  # lossless under any cookie (tests/conformance_test.go:282-291)
+                        assert (got[2] == 0).all()
+                        for i in range(b.n):
+                            nb = int(b.frames[i]) * bpf
+                            assert np.array_equal(got[0][i, :nb], b.pcm[i, :nb])
+                    mixed = helpers.mutate_packets(b, rng, 150) + [b.packet(i) for i in range(0, b.n, 5)]
+                    blob, offs, sizes = helpers.pack_packets(mixed)
+                    ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=8)
+                    helpers.assert_same_decode(cfg, ref, _gpu_decode(dec, blob, offs, sizes), bpf,
+                                               "damaged, pb %d mb %d %d-bit %d-ch profile %d" % (pb, mb, depth, ch, prof))
+                if mb in (10, 255):
+                    loud = helpers.loud_packets(synth, cfg, 80, seed=pb + depth + mb)
+                    blob, offs, sizes = helpers.pack_packets([q for q, _ in loud])
+                    ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=8)
+                    assert (ref[2] == 0).all()
+                    got = _gpu_decode(dec, blob, offs, sizes)
+                    helpers.assert_same_decode(cfg, ref, got, bpf, "loud, pb %d mb %d %d-bit %d-ch" % (pb, mb, depth, ch))
+                    for i, (_, pcm) in enumerate(loud):
+                        assert got[0][i, :len(pcm)].tobytes() == pcm
+
+
+@pytest.mark.parametrize("depth,ch,fl,n", [(16, 2, 8192, 200), (16, 2, 16384, 140), (24, 2, 8192, 140), (24, 2, 16384, 100),
+                                              (24, 8, 8192, 40), (16, 6, 16384, 24), (32, 2, 16384, 70), (20, 1, 16384, 130),
+                                              (16, 2, 65536, 66), (16, 2, 65537, 40), (24, 2, 70000, 24), (16, 1, 100000, 30)])
+def test_long_frames_match_oracle(pkg, oracle, synth, helpers, gpu_decoder_factory, depth, ch, fl, n):
+    """FrameLength is any uint32 of the cookie (config.go:70); Apple's encoder goes to 16 384 (docs/research/ENCODERS.md:79).
+    Up to 65 536 frames a mono / stereo packet stays regular (alac_regular.h: classify_regular): the U tile, the rings'
+    `near` logic and bit positions of 16 384 x 2 x 33 bits at sizes four and sixteen times the benchmark's; above 65 536 the
+    scan route; 8 and 6 channels through scan -> predictor pass -> interleave with rows of 16 384 samples. MUSIC and QUIET
+    give back the source PCM (tests/conformance_test.go:282-291); STRESS (partial frames, every order, escape elements) and
+    damaged packets are the oracle's byte for byte."""
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    rng = np.random.default_rng(fl + depth)
+    with gpu_decoder_factory(cfg) as dec:
+        for prof, k in ((synth.PROFILE_MUSIC, n), (synth.PROFILE_STRESS, max(8, n // 2)), (synth.PROFILE_QUIET, max(8, n // 3)),
+                        (synth.PROFILE_NOISE, max(4, n // 8))):
+            b = synth.gen_batch(cfg, k, profile=prof, base_seed=fl + prof, threads=16)
+            ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=16)
+            got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
+            helpers.assert_same_decode(cfg, ref, got, bpf, "%d frames, profile %d" % (fl, prof))
+            if prof != synth.PROFILE_STRESS and not (depth == 32 and ch == 2 and prof == synth.PROFILE_NOISE):
+                assert (got[2] == 0).all()
+                for i in range(b.n):
+                    nb = int(b.frames[i]) * bpf
+                    assert np.array_equal(got[0][i, :nb], b.pcm[i, :nb])
+            if prof == synth.PROFILE_MUSIC:
+                mixed = helpers.mutate_packets(b, rng, 40) + [b.packet(i) for i in range(0, b.n, 7)]
+                blob, offs, sizes = helpers.pack_packets(mixed)
+                ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=16)
+                helpers.assert_same_decode(cfg, ref, _gpu_decode(dec, blob, offs, sizes), bpf, "%d frames, damaged" % fl)
 
 
 def test_ragged_and_empty_batches(pkg, oracle, synth, helpers, gpu_decoder_factory):

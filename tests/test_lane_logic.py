@@ -49,6 +49,46 @@ def test_lane_matches_oracle_on_corrupt_packets(oracle, synth, lane_sim, helpers
         assert len(np.unique(ref[2])) > 3  # the corpus really reaches several error classes
 
 
+@pytest.mark.parametrize("pb", [0, 1, 20, 39, 41, 73, 74, 127, 255])
+def test_lane_matches_oracle_on_other_cookie_bytes(oracle, synth, lane_sim, helpers, pb):
+    """PB and MB come from the file's magic cookie (config.go:72-73) and are not 40 / 10 by any law. lean_config
+    (alac_regular.h) lets PB <= 73 take the lean Golomb step — effective pb = PB * pbFactor / 4 <= 127
+    (decoder.go:296-299), where mean < 2^25 + 512 and pb * mean cannot wrap — and sends larger ones to the whole-packet
+    decoder with the reference's literal uint32 arithmetic (golomb.go:215): both sides of that edge, the extremes, and
+    MB 0 / 1 / 255 as the first mean (golomb.go:157), on MUSIC / QUIET / NOISE / STRESS (pbFactor 0..7) streams, damaged
+    packets, and `loud` packets that hold the mean at the top of its range with pbFactor 7."""
+    rng = np.random.default_rng(pb)
+    for mb in (0, 1, 10, 255):
+        for depth, ch, fl in ((16, 2, 300), (16, 1, 200), (24, 2, 128), (16, 6, 64), (20, 2, 96), (32, 1, 80)):
+            cfg = oracle.make_config(fl, depth, ch, pb=pb, mb=mb)
+            bpf = ch * oracle.bytes_per_sample(depth)
+            for prof in (synth.PROFILE_MUSIC, synth.PROFILE_QUIET, synth.PROFILE_STRESS, synth.PROFILE_NOISE):
+                b = synth.gen_batch(cfg, 32, profile=prof, base_seed=pb * 1000 + mb, threads=4)
+                ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=4)
+                for variant in (-1, -2, 3):
+                    got = lane_sim(cfg, b.blob, b.offsets, b.sizes, variant=variant)
+                    helpers.assert_same_decode(cfg, ref, got, bpf, "pb %d mb %d profile %d variant %d" % (pb, mb, prof, variant))
+                if prof != synth.PROFILE_STRESS:  # lossless under any cookie (tests/conformance_test.go:282-291)
+                    assert (ref[2] == 0).all()
+                    for i in range(b.n):
+                        assert np.array_equal(ref[0][i, :int(b.frames[i]) * bpf], b.pcm[i, :int(b.frames[i]) * bpf])
+                blob, offs, sizes = helpers.pack_packets(helpers.mutate_packets(b, rng, 100))
+                ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=4)
+                for variant in (-1, 3):
+                    got = lane_sim(cfg, blob, offs, sizes, variant=variant)
+                    helpers.assert_same_decode(cfg, ref, got, bpf, "damaged, pb %d mb %d profile %d variant %d" % (pb, mb, prof, variant))
+            if mb == 10:
+                loud = helpers.loud_packets(synth, cfg, 12, seed=pb + depth)
+                blob, offs, sizes = helpers.pack_packets([q for q, _ in loud])
+                ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=4)
+                assert (ref[2] == 0).all()
+                for i, (_, pcm) in enumerate(loud):
+                    assert ref[0][i, :len(pcm)].tobytes() == pcm
+                for variant in (-1, -2, 3):
+                    helpers.assert_same_decode(cfg, ref, lane_sim(cfg, blob, offs, sizes, variant=variant), bpf,
+                                               "loud, pb %d variant %d" % (pb, variant))
+
+
 @pytest.mark.parametrize("depth,ch,fl", [(16, 2, 33), (16, 2, 47), (16, 2, 1000), (16, 1, 4095), (24, 2, 129),
                                          (20, 1, 65), (32, 2, 200), (16, 2, 4097)])
 def test_wave_pair_chunk_tails(oracle, synth, lane_sim, helpers, depth, ch, fl):
@@ -118,17 +158,18 @@ def test_wide_channels_take_the_wave_pair(oracle, synth, lane_sim, helpers, dept
 
 
 def test_lane_logic_reproduces_the_hand_derived_packets(oracle, lane_sim):
-    """K1..K19 (tests/golden/kat*.json, derived on paper from the reference source) through the kernel's decode logic
+    """K1..K22 (tests/golden/kat*.json, derived on paper from the reference source) through the kernel's decode logic
     as built for the host: every routing the GPU library can take for them."""
     import json
     import os
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("kat.json", "kat2.json", "kat3.json"):
+    for name in ("kat.json", "kat2.json", "kat3.json", "kat4.json"):
         k = json.load(open(os.path.join(here, "golden", name)))
         c = k["config_common"]
         for v in k["vectors"]:
             depth = v.get("bit_depth", c.get("bit_depth"))
-            cfg = oracle.make_config(v["frame_length"], depth, v["num_channels"], c["pb"], v.get("mb", c.get("mb")), c["kb"], c["max_run"])
+            cfg = oracle.make_config(v["frame_length"], depth, v["num_channels"], v.get("pb", c.get("pb")), v.get("mb", c.get("mb")), c["kb"],
+                                     c["max_run"])
             pkt = np.frombuffer(bytes.fromhex(v["packet"].replace(" ", "")), np.uint8)
             want = bytes.fromhex(v["pcm"].replace(" ", ""))
             for variant in (-1, -2, 3):

@@ -69,14 +69,32 @@ def test_hand_derived_packets_of_round_3(oracle, vec):
     assert pcm.hex().upper() == vec["pcm"].upper()
 
 
+def _kat4():
+    return json.load(open(os.path.join(HERE, "golden", "kat4.json")))
+
+
+@pytest.mark.parametrize("vec", _kat4()["vectors"], ids=lambda v: v["name"].split()[0])
+def test_hand_derived_packets_with_other_cookie_bytes(oracle, vec):
+    """K20..K22 (tests/golden/kat_derivation.md, third part): PB 20 / 73 / 255 with pbFactor 6 / 7 / 7 (pb 30, 127 and 446:
+    pb * mean wraps in uint32, golomb.go:215) and MB 0 / 255 / 1 as the first mean (config.go:72-73, decoder.go:296-299)."""
+    c = _kat4()["config_common"]
+    cfg = oracle.make_config(vec["frame_length"], vec["bit_depth"], vec["num_channels"], vec["pb"], vec["mb"], c["kb"],
+                             c["max_run"])
+    st, frames, pcm = oracle.decode_packet(cfg, bytes.fromhex(vec["packet"]))
+    assert st == 0
+    assert frames == vec["frame_length"]
+    assert pcm.hex().upper() == vec["pcm"].upper()
+
+
 def test_kat2_json_is_what_kat_build_packs():
-    """kat2.json / kat3.json are the output of tests/golden/kat_build.py (a bit packer + typed-in expectations), nothing else."""
+    """kat2.json / kat3.json / kat4.json are the output of tests/golden/kat_build.py (a bit packer + typed-in expectations), nothing else."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("kat_build", os.path.join(HERE, "golden", "kat_build.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.build() == _kat2()["vectors"]
     assert m.build3() == _kat3()["vectors"]
+    assert m.build4() == _kat4()["vectors"]
 
 
 def test_golden_packets(oracle):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""gpu_fuzz.py — one-off randomized parity sweep on the GPU: random frame lengths, depths, channel counts, signal
-profiles, batch sizes and wave widths, intact and corrupted packets, HIP path vs oracle through the C ABI.
+"""gpu_fuzz.py — one-off randomized parity sweep on the GPU: random frame lengths (now and then 8 192 .. 70 000 frames),
+depths, channel counts, signal profiles, batch sizes, wave widths and cookie bytes KB / PB / MB (config.go:72-74), intact,
+`loud` and corrupted packets, HIP path vs oracle through the C ABI.
 usage: python tools/gpu_fuzz.py [rounds] [seed]"""
 import importlib, os, sys
 import numpy as np
@@ -10,7 +11,7 @@ import torch  # noqa: F401  (one HIP runtime per process: torch first)
 pkg = importlib.import_module("saprobe-alac_amd")
 synth = importlib.import_module("saprobe-alac_amd.synth")
 from oracle import oracle
-from conftest import mutate_packets, pack_packets, assert_same_decode
+from conftest import mutate_packets, pack_packets, assert_same_decode, loud_packets
 synth.build(); oracle.build()
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -38,15 +39,29 @@ for r in range(rounds):
     if rng.integers(10) == 0 and fl < 300 and ch <= 2:  # full 64-packet workgroups with one or less per CU: both predictor waves at work
         n = int(rng.choice([16400, 16500, 17000]))
     kb = int(rng.choice([14, 14, 14, 14, 3, 32, 255, 0]))
-    cfg = oracle.make_config(fl, depth, ch, kb=kb)
+    # PB / MB: cookie bytes too. PB <= 73 keeps the lean Golomb step (alac_regular.h: lean_config), above it the whole-packet decoder
+    pb = int(rng.choice([40, 40, 40, 0, 1, 20, 39, 41, 72, 73, 74, 100, 127, 128, 255, int(rng.integers(0, 256))]))
+    mb = int(rng.choice([10, 10, 10, 0, 1, 127, 128, 255, int(rng.integers(0, 256))]))
+    if rng.integers(25) == 0 and n <= 700:  # long frames: Apple's encoder goes to 16 384 (docs/research/ENCODERS.md:79); > 65 536: the scan route
+        fl = int(rng.choice([8192, 16384, int(rng.integers(4097, 20000)), 65536, 65537, 70000]))
+        n = int(rng.choice([1, 7, 64, 65])) if fl < 60000 else int(rng.choice([1, 7, 20]))
+    cfg = oracle.make_config(fl, depth, ch, pb=pb, mb=mb, kb=kb)
     bpf = ch * oracle.bytes_per_sample(depth)
     try:
         b = synth.gen_batch(cfg, n, profile=prof, base_seed=int(rng.integers(1 << 30)), threads=8)
     except RuntimeError:
         continue  # the encoder has no code for this residual under this KB
     blob, offs, sizes = b.blob, b.offsets, b.sizes
-    if rng.integers(3) == 0:
+    what = rng.integers(6)
+    if what < 2:
         blob, offs, sizes = pack_packets(mutate_packets(b, rng, n))
+    elif what == 2 and fl <= 5000 and n <= 700:  # the mean at the top of its range (conftest.loud_packets) among the others
+        try:
+            lp = [q for q, _ in loud_packets(synth, cfg, max(1, n // 2), seed=int(rng.integers(1 << 30)), pb_factor=int(rng.choice([7, 7, 4, 5])),
+                                             order=int(rng.choice([0, 0, 4, 31])))]
+        except RuntimeError:
+            lp = []
+        blob, offs, sizes = pack_packets(lp + [b.packet(i) for i in range(n - len(lp))])
     ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=8)
     c = pkg.PacketConfig(FrameLength=fl, BitDepth=depth, NumChannels=ch, PB=cfg.pb, MB=cfg.mb, KB=cfg.kb,
                          MaxRun=cfg.max_run, SampleRate=cfg.sample_rate)
@@ -62,7 +77,7 @@ for r in range(rounds):
         assert_same_decode(cfg, ref, (out, fr, st), bpf, "round %d" % r)
     except AssertionError as e:
         bad += 1
-        print("MISMATCH depth %d ch %d fl %d prof %d n %d ppw %r kb %d lanes_min %r: %s" % (depth, ch, fl, prof, n, ppw, kb, lm, e), flush=True)
+        print("MISMATCH depth %d ch %d fl %d prof %d n %d ppw %r kb %d pb %d mb %d lanes_min %r what %d: %s" % (depth, ch, fl, prof, n, ppw, kb, pb, mb, lm, what, e), flush=True)
     if r % 50 == 49:
         print("round %d" % (r + 1), flush=True)
 print("%d rounds, %d mismatches" % (rounds, bad))
