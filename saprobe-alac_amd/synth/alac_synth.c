@@ -69,6 +69,10 @@ typedef struct {
 
 static void bw_put(bitw* w, uint32_t val, uint32_t nbits) {
     if (nbits == 0) return;
+    if (nbits > 32) { /* no such field exists: a caller's parameter is out of range (see ag_encode) */
+        w->overflow = 1;
+        return;
+    }
     if (nbits < 32) val &= (1u << nbits) - 1u;
     size_t byte = (size_t)(w->bitpos >> 3);
     uint32_t used = (uint32_t)(w->bitpos & 7);
@@ -138,6 +142,13 @@ static void ag_encode(bitw* w, const int32_t* res, uint32_t n, uint32_t mb, uint
             zmode = 1;
             int32_t k32 = lead(mean) - 24 + (int32_t)((mean + 16) >> 6);
             if (k32 < 0) k32 = 0;
+            /* With pb > 127 the product pb * mean wraps (golomb.go:215), the mean no longer contracts and can pass 2^30,
+             * where mean << 2 wraps too and a "zero run" starts with k32 in the millions: the reference then jumps
+             * millions of bits ahead (dynGet, golomb.go:131-139) and fails. Nothing can be encoded for that state. */
+            if (k32 > 24) {
+                w->overflow = 1;
+                return;
+            }
             uint32_t mz = (go_shl(1, (uint32_t)k32) - 1) & wb;
             uint32_t run = 0;
             while (c + run < n && res[c + run] == 0 && run < 65535) run++;

@@ -7,7 +7,9 @@ import importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-import torch  # noqa: F401  (one HIP runtime per process: torch first)
+DRY = os.environ.get("ALACGPU_FUZZ_DRY") == "1"  # generator and oracle only (no GPU): the same rounds, to tell a fault of theirs apart
+if not DRY:
+    import torch  # noqa: F401  (one HIP runtime per process: torch first)
 pkg = importlib.import_module("saprobe-alac_amd")
 synth = importlib.import_module("saprobe-alac_amd.synth")
 from oracle import oracle
@@ -47,8 +49,11 @@ for r in range(rounds):
         n = int(rng.choice([1, 7, 64, 65])) if fl < 60000 else int(rng.choice([1, 7, 20]))
     cfg = oracle.make_config(fl, depth, ch, pb=pb, mb=mb, kb=kb)
     bpf = ch * oracle.bytes_per_sample(depth)
+    base_seed = int(rng.integers(1 << 30))
+    if os.environ.get("ALACGPU_FUZZ_VERBOSE") == "2":
+        print("round %d (before the generator): depth %d ch %d fl %d prof %d n %d kb %d pb %d mb %d seed %d" % (r, depth, ch, fl, prof, n, kb, pb, mb, base_seed), flush=True)
     try:
-        b = synth.gen_batch(cfg, n, profile=prof, base_seed=int(rng.integers(1 << 30)), threads=8)
+        b = synth.gen_batch(cfg, n, profile=prof, base_seed=base_seed, threads=8)
     except RuntimeError:
         continue  # the encoder has no code for this residual under this KB
     blob, offs, sizes = b.blob, b.offsets, b.sizes
@@ -63,6 +68,11 @@ for r in range(rounds):
             lp = []
         blob, offs, sizes = pack_packets(lp + [b.packet(i) for i in range(n - len(lp))])
     ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=8)
+    if os.environ.get("ALACGPU_FUZZ_VERBOSE"):
+        print("round %d: depth %d ch %d fl %d prof %d n %d ppw %r kb %d pb %d mb %d lanes_min %r what %d" % (r, depth, ch, fl, prof, len(offs), ppw, kb, pb, mb, lm, what), flush=True)
+    if DRY:
+        rng.integers(0, 4)
+        continue
     c = pkg.PacketConfig(FrameLength=fl, BitDepth=depth, NumChannels=ch, PB=cfg.pb, MB=cfg.mb, KB=cfg.kb,
                          MaxRun=cfg.max_run, SampleRate=cfg.sample_rate)
     with pkg.NewPacketDecoder(c, 0) as dec:
