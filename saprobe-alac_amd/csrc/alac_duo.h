@@ -153,13 +153,14 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
     /* A: residuals of chunk c (DynDecomp, golomb.go:167-247). Whole chunks run as straight-line groups of four steps (the bitstream ring is topped
      * up once per group, 4 steps ahead of need). */
     uint32_t ns_live = s.err == 0 ? ns : 0u;
+    if (DO_A) gol_head(s, c31kb); /* the head of the channel's first step (gol_step) */
     auto qval = [&](uint32_t nd) -> int32_t { return QND ? (int32_t)nd : gol_unfold(nd); };
     auto golomb_chunk = [&](uint32_t c) {
         const uint32_t buf = c & 1u;
         if ((c + 1u) * CH <= n_it) { /* CH is 8 or 16: whole top-up periods */
 #pragma nounroll
             for (uint32_t g = 0; g < CH; g += GOL_TICK) {
-                s.rd.tick(wv);
+                s.rd.tick(wv, s.pos);
                 s.near = gol_near(s, c * CH + g, ns_live);
 #pragma nounroll
                 for (uint32_t h = g; h < g + GOL_TICK; h += 4u) {
@@ -175,7 +176,7 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
             const uint32_t i = c * CH + j;
             if (i >= n_it) break;
             if ((i & (GOL_TICK - 1u)) == 0) {
-                s.rd.tick(wv);
+                s.rd.tick(wv, s.pos);
                 s.near = gol_near(s, i, ns_live);
             }
             wv.rq_write(buf, j, qval(gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i, ns, ns_live)));
@@ -623,23 +624,32 @@ ALAC_DEV void duo_phase(W& wv, const DevCfg& cfg, const B& bits, RegLane<W>& s, 
 }
 
 /*
- * Role B on TWO LANES PER PACKET (round 3): the predictor waves of the four-wave workgroups (k_dec16q.hip), for keys with
- * a long predictor. A predictor step costs ten instructions per tap and a workgroup's step is its longest wave's: with
- * twelve taps role B needs 128 instructions against the entropy wave's 66, and the 5 % of the benchmark's packets that
- * have them kept the whole batch waiting (65 536 packets: 2.43 ms, 2.04 ms without them). Such a workgroup gets a second
- * predictor wave; each of the two holds 32 of the 64 packets, a packet's taps spread over a DPP pair: lane q holds taps
- * q T .. q T + T - 1 (T = ceil(order / 2)), the prediction is the sum over the pair, what the upper lane's taps take off
- * the adaptation countdown (alac_regular.h: predict_narrow_core) reaches the lower lane by one DPP move, the history
- * moves by renaming and one DPP move, the sample enters at lane 0. ~10 T + 20 instructions per step. The order is
- * wave-uniform (one key per workgroup), so top = out[i - 1 - order] sits at a fixed place of lane 1.
+ * Role B on SEVERAL LANES PER PACKET: the predictor waves of the four-wave workgroups (k_dec16q.hip) in small batches. A
+ * predictor step costs eight instructions per tap and a workgroup's step is its longest wave's: with twelve taps role B
+ * needs 120 instructions against the entropy wave's ~45, and while every workgroup has a CU to itself nothing else fills
+ * the SIMD: a lone wave issues an instruction every 4.8 cycles, so a packet's time IS its longest wave's instruction count
+ * (profiles/r04_final/single_packets.txt: 1.15 / 1.38 ms for six / eight taps on one lane). So a packet's taps are spread
+ * over LPP = 2 (round 3) or 4 (round 4) neighbouring lanes of a predictor wave: lane q holds taps q T .. q T + T - 1
+ * (T = ceil(order / LPP)), the prediction is the sum over the group (DPP adds), what the higher lanes' taps take off the
+ * adaptation countdown (alac_regular.h: predict_narrow_core) reaches the lower lanes by DPP moves — the t_j do not depend
+ * on the countdown, so every lane's starting value is |del| minus the sum over the lanes above it —, the history moves
+ * by renaming and one DPP move, the sample enters at lane 0. ~10 T + 30 instructions per step. The order is wave-uniform
+ * (one key per workgroup), so top = out[i - 1 - order] sits at a fixed place: lane (order - 1) / T, register
+ * order - that * T. A wave holds 64 / LPP packets: two predictor waves (roles 1 and 3) cover 64 packets on two lanes and 32
+ * on four (batches of up to 16 383 packets: alacgpu.hip: pick_ppw).
  * Protocol, queue and hand-off rows exactly as role B of duo_phase() in a workgroup with a writer wave (EC): residuals
  * come as n + zmode, U samples go to the hand-off tile, the samples of the last channel to rows CH.. of the queue buffer
  * for the writer wave. wv.lane is the packet's COLUMN (its lane in the entropy and writer waves), q the lane's number in
- * its pair. chanBits <= 23 only.
+ * its group. chanBits <= 23 only.
  */
-template <class W, class B, int T, int OUT>
+/* NAC: the order as a compile-time constant (four lanes: where top sits is then one DPP pattern and one register, without
+ * a branch or a select in the step), 0: the wave-uniform run-time value na (two lanes: one select) */
+template <class W, class B, int T, int OUT, int LPP, int NAC = 0>
 ALAC_DEV void duo_phase_lanes(W& wv, const B& bits, uint32_t q, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift,
-                              uint32_t chan_bits, uint32_t na) {
+                              uint32_t chan_bits, uint32_t na_rt) {
+    static_assert(LPP == 2 || LPP == 4, "lanes per packet");
+    static_assert(LPP == 2 ? NAC == 0 : (NAC >= 1 && (NAC + 3) / 4 == T), "four lanes: T = ceil(order / 4)");
+    const uint32_t na = NAC != 0 ? (uint32_t)NAC : na_rt;
     constexpr bool LAST = OUT != OUT_UTILE;
     constexpr uint32_t CH = LAST ? DUO_CHUNK / 2u : DUO_CHUNK;
     constexpr uint32_t BIAS = 0x80000000u;
@@ -649,6 +659,8 @@ ALAC_DEV void duo_phase_lanes(W& wv, const B& bits, uint32_t q, uint32_t n_it, u
     const int32_t dh0 = q == 0u ? den_half : 0; /* the rounding term enters the sum once */
     const uint32_t rnd_neg = (1u << den_shift) - 1u;
     const uint32_t q0m = q == 0u ? 0xffffffffu : 0u;
+    /* (four lanes) which of the lanes above this one exist: lane q takes the sums of lanes q + 1 .. 3 */
+    const uint32_t up1 = q < 3u ? 0xffffffffu : 0u, up2 = q < 2u ? 0xffffffffu : 0u, up3 = q < 1u ? 0xffffffffu : 0u;
     int32_t coef[T], wneg[T], m[T];
     uint32_t g[T + 1]; /* g[t] = out[i - 1 - (q T + t)] ^ BIAS */
 #pragma unroll
@@ -662,12 +674,16 @@ ALAC_DEV void duo_phase_lanes(W& wv, const B& bits, uint32_t q, uint32_t n_it, u
     }
     g[T] = BIAS;
     int32_t prev = 0;
-    const bool top_last = na == 2u * (uint32_t)T; /* top = out[i - 1 - na]: lane 1's g[T] (g[T - 1] when the order is odd) */
+    /* top = out[i - 1 - na]: g[TTOP] of lane QTOP (two lanes: lane 1's g[T], g[T - 1] when the order is odd) */
+    constexpr int QTOP = NAC != 0 ? (NAC - 1) / T : 1, TTOP = NAC != 0 ? NAC - QTOP * T : T; /* TTOP = 1..T */
+    const bool top_last = na == 2u * (uint32_t)T; /* (two lanes) */
 
     /* one step: sample i from what the entropy wave queued (nd = n + zmode, golomb.go:206-209). PLAIN: i > order. */
     auto step = [&](uint32_t i, uint32_t nd, auto plain_c, auto wrap_c) -> int32_t {
         constexpr bool PLAIN = decltype(plain_c)::value, WR = decltype(wrap_c)::value;
-        const uint32_t topb = wv.pair_hi(top_last ? g[T] : g[T - 1]);
+        uint32_t topb;
+        if constexpr (LPP == 2) topb = wv.pair_hi(top_last ? g[T] : g[T - 1]);
+        else topb = wv.template quad_from<QTOP>(g[TTOP]);
         const uint32_t nsg = nd & 1u, sgnm = 0u - nsg, hm = nd >> 1;
         const int32_t del = (int32_t)(hm ^ sgnm);
         int32_t rem = (int32_t)(hm + nsg); /* |del| */
@@ -692,7 +708,10 @@ ALAC_DEV void duo_phase_lanes(W& wv, const B& bits, uint32_t q, uint32_t n_it, u
                 s = ALAC_MUL24((int32_t)qv[t], wneg[t]) + s;
             }
         }
-        rem += (int32_t)(wv.pair_hi((uint32_t)s) & q0m); /* minus what the upper lane's taps take away */
+        /* minus what the taps of the lanes above take away */
+        if (LPP == 2) rem += (int32_t)(wv.pair_hi((uint32_t)s) & q0m);
+        else rem += (int32_t)((wv.template quad_up<1>((uint32_t)s) & up1) + (wv.template quad_up<2>((uint32_t)s) & up2) +
+                              (wv.template quad_up<3>((uint32_t)s) & up3));
 #pragma unroll
         for (int t = T - 1; t >= 0; --t) {
             const int32_t go = ALAC_MED3_0(rem, m[t]);
@@ -702,13 +721,14 @@ ALAC_DEV void duo_phase_lanes(W& wv, const B& bits, uint32_t q, uint32_t n_it, u
             if (WR) cj = (int32_t)(int16_t)cj; /* predictor.go:664,675 */
             coef[t] = cj;
         }
-        const int32_t at = wv.pair_sum(acc);
+        const int32_t at = LPP == 2 ? wv.pair_sum(acc) : wv.quad_sum(acc);
         int32_t o = ALAC_SEXT_BITS(del + (int32_t)(topb ^ BIAS) + (at >> den_shift), chan_bits);
         if (!PLAIN) {
             if (i == 0u) o = del; /* out[0] = pc1[0] */
             else if (i <= na) o = sext_cs(del + prev, chan_shift); /* predictor.go:63-79 */
         }
-        const uint32_t g0 = wv.pair_from_below(g[T - 1], (uint32_t)o ^ BIAS, q0m); /* the tap below a lane's first comes from the lane before */
+        /* the tap below a lane's first comes from the lane before */
+        const uint32_t g0 = LPP == 2 ? wv.pair_from_below(g[T - 1], (uint32_t)o ^ BIAS, q0m) : wv.quad_from_below(g[T - 1], (uint32_t)o ^ BIAS, q0m);
 #pragma unroll
         for (int t = T; t >= 1; --t) g[t] = g[t - 1];
         g[0] = g0;
@@ -718,7 +738,7 @@ ALAC_DEV void duo_phase_lanes(W& wv, const B& bits, uint32_t q, uint32_t n_it, u
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
     auto put = [&](uint32_t buf, uint32_t k, uint32_t i, int32_t o) {
-        if (!LAST) *wv.u_row(i) = o; /* both lanes of the pair store the same value to the packet's cell */
+        if (!LAST) *wv.u_row(i) = o; /* every lane of the group stores the same value to the packet's cell */
         else wv.rq_write(buf, CH + k, o);
     };
     auto predict_chunk = [&](uint32_t cc) {
@@ -764,24 +784,34 @@ ALAC_DEV void duo_phase_lanes(W& wv, const B& bits, uint32_t q, uint32_t n_it, u
 }
 
 /* taps per lane by the (wave-uniform) order, 3..16 (duo_lanes_key) */
-template <class W, int OUT, class B>
+template <class W, int OUT, int LPP, class B>
 ALAC_DEV void duo_phase_lanes_na(W& wv, uint32_t na, const B& bits, uint32_t q, uint32_t n_it, uint32_t hdr_pos, uint32_t den_shift,
                                  uint32_t chan_bits) {
-    switch ((na + 1u) / 2u) {
-        case 0:
-        case 1:
-        case 2: duo_phase_lanes<W, B, 2, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
-        case 3: duo_phase_lanes<W, B, 3, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
-        case 4: duo_phase_lanes<W, B, 4, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
-        case 5: duo_phase_lanes<W, B, 5, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
-        case 6: duo_phase_lanes<W, B, 6, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
-        case 7: duo_phase_lanes<W, B, 7, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
-        default: duo_phase_lanes<W, B, 8, OUT>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+    if constexpr (LPP == 4) {
+#define ALAC_L4(N) \
+    case N: duo_phase_lanes<W, B, (N + 3) / 4, OUT, 4, N>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+        switch (na) { /* 3..16 (duo_lanes_key) */
+            ALAC_L4(3) ALAC_L4(4) ALAC_L4(5) ALAC_L4(6) ALAC_L4(7) ALAC_L4(8) ALAC_L4(9) ALAC_L4(10) ALAC_L4(11) ALAC_L4(12)
+            ALAC_L4(13) ALAC_L4(14) ALAC_L4(15)
+            default: duo_phase_lanes<W, B, 4, OUT, 4, 16>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+        }
+#undef ALAC_L4
+    } else {
+        switch ((na + 1u) / 2u) {
+            case 0:
+            case 1:
+            case 2: duo_phase_lanes<W, B, 2, OUT, 2>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+            case 3: duo_phase_lanes<W, B, 3, OUT, 2>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+            case 4: duo_phase_lanes<W, B, 4, OUT, 2>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+            case 5: duo_phase_lanes<W, B, 5, OUT, 2>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+            case 6: duo_phase_lanes<W, B, 6, OUT, 2>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+            case 7: duo_phase_lanes<W, B, 7, OUT, 2>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+            default: duo_phase_lanes<W, B, 8, OUT, 2>(wv, bits, q, n_it, hdr_pos, den_shift, chan_bits, na); break;
+        }
     }
 }
 
-/* keys the two-lane predictor waves take: every order 3..16 (T = ceil(order / 2) >= 2 puts top at lane 1's g[T] or
- * g[T - 1]) and the longer one at least `lanes_min` */
+/* keys the several-lane predictor waves take: every order 3..16 and the longer one at least `lanes_min` */
 ALAC_DEV bool duo_lanes_key(uint32_t key, bool cpe, uint32_t lanes_min) {
     const uint32_t nu = (key >> 5) & 31u, nv = key & 31u;
     if ((key & KEY_WIDE) != 0u || nu < 3u || nu > 16u) return false;
@@ -854,10 +884,10 @@ ALAC_DEV void duo_phase_na(W& wv, uint32_t na, const DevCfg& cfg, const B& bits,
  */
 /* EC: the caller's workgroup has a third wave (ROLE_C) that writes the PCM of the narrow phases (duo_phase); its return
  * value and *frames_out mean nothing either. */
-/* LANES: the caller is a predictor wave on two lanes per packet (duo_phase_lanes; wv.lane = the packet's column, q = the
- * lane's number in its pair); ns_other: the frame count of the packet in the same column of the workgroup's other
+/* LANES 2 / 4: the caller is a predictor wave on that many lanes per packet (duo_phase_lanes; wv.lane = the packet's column,
+ * q = the lane's number in its group); ns_other: the frame count of the packet in the same column of the workgroup's other
  * predictor wave, so that both agree with the entropy wave on the number of steps. */
-template <class W, int ROLE, int WIDE_SEL = -1, int DEPTH_SEL = 0, bool EC = false, bool LANES = false>
+template <class W, int ROLE, int WIDE_SEL = -1, int DEPTH_SEL = 0, bool EC = false, int LANES = 0>
 ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool live, const uint8_t* pkt, uint32_t size,
                                     uint32_t avail, uint8_t* out, uint32_t* frames_out, uint32_t q = 0u, uint32_t ns_other = 0u) {
     constexpr bool DO_A = ROLE == ROLE_A || ROLE == ROLE_BOTH, DO_B = ROLE == ROLE_B || ROLE == ROLE_BOTH;
@@ -895,18 +925,18 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     const uint32_t hv = bits.get(hdr_v, 16);
     const uint32_t bs = (bits.get(19, 4) >> 1) & 3u;
     const uint32_t shift_pos = cpe ? hdr_v + 16u + 16u * na_v : hdr_v; /* decoder.go:289-293, 453-457 */
-    s.pos = shift_pos + bs * 8u * (cpe ? 2u : 1u) * ns + s.rd.bias;
+    s.set_upos(shift_pos + bs * 8u * (cpe ? 2u : 1u) * ns);
     const uint32_t chan_bits = cfg.bit_depth - 8u * bs + (cpe ? 1u : 0u);
     /* the 16- and 20-bit writers ignore the shift buffer (matrix.go:30,66) */
     const uint32_t sb = (cfg.bit_depth == 24 || cfg.bit_depth == 32) ? bs * 8u : 0u;
-    const uint32_t n_it = wv.max_u32(LANES ? umax(ns, ns_other) : ns);
-    if constexpr (LANES) {
+    const uint32_t n_it = wv.max_u32(LANES != 0 ? umax(ns, ns_other) : ns);
+    if constexpr (LANES != 0) {
         static_assert(ROLE == ROLE_B && EC && WIDE_SEL == 0, "a predictor wave beside an entropy and a writer wave, narrow channels");
         if (cpe) {
-            duo_phase_lanes_na<W, OUT_UTILE>(wv, na_u, bits, q, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits);
-            duo_phase_lanes_na<W, OUT_STEREO>(wv, na_v, bits, q, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits);
+            duo_phase_lanes_na<W, OUT_UTILE, LANES>(wv, na_u, bits, q, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits);
+            duo_phase_lanes_na<W, OUT_STEREO, LANES>(wv, na_v, bits, q, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits);
         } else {
-            duo_phase_lanes_na<W, OUT_MONO>(wv, na_u, bits, q, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits);
+            duo_phase_lanes_na<W, OUT_MONO, LANES>(wv, na_u, bits, q, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits);
         }
         return 0;
     }
@@ -918,8 +948,8 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
     /* ---- U (or the mono channel) ---- */
     s.mean = cfg.mb;
     s.zmode = 0;
-    s.zrem = 0;
-    s.pb = (cfg.pb * ((hu >> 5) & 7u)) / 4u; /* decoder.go:299 */
+    s.zq = 0xffffffffu;
+    s.set_pb((cfg.pb * ((hu >> 5) & 7u)) / 4u); /* decoder.go:299 */
     if (DO_A) s.rd.start(wv, live ? s.pos : s.rd.bias);
     if constexpr (WIDE_SEL != 1) if (!wide) {
         if (cpe) duo_phase_na<W, OUT_UTILE, ROLE, false, true, false, EC>(wv, na_u, cfg, bits, s, size, ns, n_it, hdr_u, (hu >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, 0u);
@@ -937,8 +967,8 @@ ALAC_DEV int32_t decode_regular_duo(W& wv, const DevCfg& cfg, uint32_t key, bool
         const int32_t err_u = s.err;
         s.mean = cfg.mb;
         s.zmode = 0;
-        s.zrem = 0;
-        s.pb = (cfg.pb * ((hv >> 5) & 7u)) / 4u;
+        s.zq = 0xffffffffu;
+        s.set_pb((cfg.pb * ((hv >> 5) & 7u)) / 4u);
         if (DO_A) s.rd.start(wv, (live && s.err == 0) ? s.pos : s.rd.bias);
         if constexpr (WIDE_SEL != 0) if (wide)
             duo_phase_na<W, OUT_STEREO, ROLE, false, false, false, false, WM>(wv, na_v, cfg, bits, s, size, ns, n_it, hdr_v, (hv >> 8) & 0xfu, chan_bits, mix_res, mix_sh, shift_pos, sb);

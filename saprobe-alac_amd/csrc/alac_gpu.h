@@ -53,6 +53,12 @@ __device__ __forceinline__ uint32_t alac_xad(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 #define ALAC_XAD(a, b, c) alac_xad((uint32_t)(a), (uint32_t)(b), (uint32_t)(c))
+__device__ __forceinline__ uint32_t alac_not_add(uint32_t a, uint32_t c) {
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, -1, %2" : "=v"(r) : "v"(a), "v"(c));
+    return r;
+}
+#define ALAC_NOT_ADD(a, c) alac_not_add((uint32_t)(a), (uint32_t)(c))
 __device__ __forceinline__ uint32_t alac_bfi(uint32_t m, uint32_t a, uint32_t b) {
     uint32_t r;
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
@@ -93,12 +99,71 @@ __device__ __forceinline__ int32_t alac_sext_bits(int32_t x, uint32_t bits) {
 }
 #define ALAC_SEXT_BITS(x, bits) alac_sext_bits((int32_t)(x), (uint32_t)(bits))
 #define ALAC_MULU24(a, b) __umul24((unsigned)(a), (unsigned)(b))
+#define ALAC_MULHI(a, b) __umulhi((unsigned)(a), (unsigned)(b))
+#define ALAC_ALIGNBIT(hi, lo, sh) __builtin_amdgcn_alignbit((unsigned)(hi), (unsigned)(lo), (unsigned)(sh))
 __device__ __forceinline__ int32_t alac_med3_0(int32_t x, int32_t m) {
     int32_t r;
     asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(m));
     return r;
 }
 #define ALAC_MED3_0(x, m) alac_med3_0((int32_t)(x), (int32_t)(m))
+/* The two blocks of the Golomb step (alac_regular.h: gol_step, whose C++ form these follow instruction for
+ * instruction), each ONE asm statement: the order inside is the order of issue, and no instruction reads the result of
+ * the one before it (a lone wave: 8.3 cycles instead of 4.8). v_cmp .. v_addc: two instructions apart (the compiler keeps
+ * the same distance). 128 is no inline constant and VOP3 takes no literal on gfx9: it comes in an SGPR. */
+#ifndef ALAC_GOL_ASM
+#define ALAC_GOL_ASM 0
+#endif
+#define ALAC_GOL_BLOCK_A(wa, wb, sh, ck, t9, norun, pos, mean, zq, pb, n, esc, mt, pos2, aoff, zq2, mean2, nhi)            \
+    do {                                                                                                                   \
+        uint32_t w_, k_, t_, pre_, v_, pk_, vm1_, cons_;                                                                   \
+        asm("v_alignbit_b32 %[w], %[Wa], %[Wb], %[Sh]\n\t"                                                                 \
+            "v_sub_u32 %[k], 31, %[Ck]\n\t"                                                                                \
+            "v_not_b32 %[t], %[w]\n\t"                                                                                     \
+            "v_sub_u32 %[Mt], %[Mean], %[T9]\n\t"                                                                          \
+            "v_ffbh_u32 %[pre], %[t]\n\t"                                                                                  \
+            "v_xad_u32 %[Zq2], %[Norun], -1, %[Zq]\n\t"                                                                    \
+            "v_sub_u32 %[t], %[Ck], %[pre]\n\t"                                                                            \
+            "v_sub_u32_e64 %[Esc], %[pre], 8 clamp\n\t"                                                                    \
+            "v_bfe_u32 %[v], %[w], %[t], %[k]\n\t"                                                                         \
+            "v_lshlrev_b32 %[pk], %[k], %[pre]\n\t"                                                                        \
+            "v_cmp_lt_u32 vcc, 1, %[v]\n\t"                                                                                \
+            "v_sub_u32_e64 %[vm1], %[v], 1 clamp\n\t"                                                                      \
+            "v_sub_u32 %[pk], %[pk], %[pre]\n\t"                                                                           \
+            "v_addc_co_u32 %[cons], vcc, %[pre], %[k], vcc\n\t"                                                            \
+            "v_add_u32 %[N], %[pk], %[vm1]\n\t"                                                                            \
+            "v_and_b32 %[cons], %[cons], %[Norun]\n\t"                                                                     \
+            "v_and_b32 %[N], %[N], %[Norun]\n\t"                                                                           \
+            "v_add_u32 %[Pos2], %[Pos], %[cons]\n\t"                                                                       \
+            "v_mad_u32_u24 %[Mean2], %[Pb], %[N], %[Mt]\n\t"                                                               \
+            "v_lshrrev_b32 %[Aoff], 3, %[Pos2]\n\t"                                                                        \
+            "v_lshrrev_b32 %[Nhi], 16, %[N]\n\t"                                                                           \
+            "v_and_b32 %[Aoff], 0x7c, %[Aoff]"                                                                             \
+            : [w] "=&v"(w_), [k] "=&v"(k_), [t] "=&v"(t_), [pre] "=&v"(pre_), [v] "=&v"(v_), [pk] "=&v"(pk_),              \
+              [vm1] "=&v"(vm1_), [cons] "=&v"(cons_), [N] "=&v"(n), [Esc] "=&v"(esc), [Mt] "=&v"(mt), [Pos2] "=&v"(pos2),  \
+              [Aoff] "=&v"(aoff), [Zq2] "=&v"(zq2), [Mean2] "=&v"(mean2), [Nhi] "=&v"(nhi)                                 \
+            : [Wa] "v"(wa), [Wb] "v"(wb), [Sh] "v"(sh), [Ck] "v"(ck), [T9] "v"(t9), [Norun] "v"(norun), [Pos] "v"(pos),    \
+              [Mean] "v"(mean), [Zq] "v"(zq), [Pb] "v"(pb)                                                                 \
+            : "vcc");                                                                                                      \
+    } while (0)
+#define ALAC_GOL_BLOCK_B(mean2, nhi, esc, pos2, zq2, norun, near, pbs, c31kb, rare, sh2, ck2, t92, norun2)                 \
+    do {                                                                                                                   \
+        uint32_t zs_, x_;                                                                                                  \
+        asm("v_sub_u32_e64 %[zs], %[C128], %[Mean2] clamp\n\t"                                                             \
+            "v_lshrrev_b32 %[x], 9, %[Mean2]\n\t"                                                                          \
+            "v_not_b32 %[Sh2], %[Pos2]\n\t"                                                                                \
+            "v_or3_b32 %[zs], %[Esc], %[Nhi], %[zs]\n\t"                                                                   \
+            "v_mul_hi_u32 %[T92], %[Mean2], %[Pbs]\n\t"                                                                    \
+            "v_add_u32 %[x], 3, %[x]\n\t"                                                                                  \
+            "v_ashrrev_i32 %[Norun2], 31, %[Zq2]\n\t"                                                                      \
+            "v_ffbh_u32 %[x], %[x]\n\t"                                                                                    \
+            "v_bitop3_b32 %[Rare], %[zs], %[Norun], %[Near] bitop3:0xc8\n\t"                                               \
+            "v_max_i32 %[Ck2], %[x], %[C31kb]"                                                                             \
+            : [zs] "=&v"(zs_), [x] "=&v"(x_), [Sh2] "=&v"(sh2), [T92] "=&v"(t92), [Norun2] "=&v"(norun2),                  \
+              [Rare] "=&v"(rare), [Ck2] "=&v"(ck2)                                                                         \
+            : [C128] "s"(128u), [Mean2] "v"(mean2), [Nhi] "v"(nhi), [Esc] "v"(esc), [Pos2] "v"(pos2), [Zq2] "v"(zq2),      \
+              [Norun] "v"(norun), [Near] "v"(near), [Pbs] "v"(pbs), [C31kb] "v"(c31kb));                                   \
+    } while (0)
 #define ALAC_PICK(dst, src) asm volatile("v_mov_b32 %0, %1" : "+v"(dst) : "v"(src))
 #define ALAC_OWN_REG(x) asm volatile("" : "+v"(x))
 typedef uint32_t alac_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -319,16 +384,49 @@ struct GpuWave {
         *reinterpret_cast<uint4*>(&s_ring[lane * kRingStride + (slot >> 2) * 4u]) = make_uint4(a, b, c, d);
     }
     ALAC_DEV uint32_t ring_read(uint32_t slot) const { return s_ring[lane * kRingStride + slot]; }
+    /* slots `slot` and `slot + 1` in one ds_read2_b32 (slot <= kRingDw - 1: slot kRingDw repeats slot 0, RingRd::commit) */
+    ALAC_DEV void ring_read2(uint32_t slot, uint32_t& a, uint32_t& b) const {
+        const uint32_t* q = &s_ring[lane * kRingStride + slot];
+        a = q[0];
+        b = q[1];
+    }
+    /* the same by the slot's byte offset in the lane's row (4 * slot) */
+    ALAC_DEV void ring_read2_at(uint32_t byte_off, uint32_t& a, uint32_t& b) const {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(&s_ring[lane * kRingStride]) + byte_off);
+        a = q[0];
+        b = q[1];
+    }
+    ALAC_DEV void ring_write1(uint32_t slot, uint32_t v) { s_ring[lane * kRingStride + slot] = v; }
     /* residual queue: row j of buffer buf holds step j of the chunk for all 64 lanes (conflict-free) */
     ALAC_DEV void rq_write(uint32_t buf, uint32_t j, int32_t v) { s_rq[(buf * kQRows + j) * kWave + lane] = v; }
     ALAC_DEV int32_t rq_read(uint32_t buf, uint32_t j) const { return s_rq[(buf * kQRows + j) * kWave + lane]; }
     /* two lanes per packet (alac_duo.h: duo_phase_lanes): DPP moves inside every pair of neighbouring lanes. Their source
      * must be the result of an instruction the compiler knows (not of inline asm): it inserts the wait states they need. */
-    ALAC_DEV uint32_t pair_hi(uint32_t x) const { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF5, 0xf, 0xf, false); } /* [1,1,3,3] */
-    ALAC_DEV int32_t pair_sum(int32_t x) const { return x + __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false); }            /* [1,0,3,2] */
+    /* (mov_dpp, not update_dpp(0, ...): every lane of a quad_perm has a source, so there is no old value to keep; with one
+     * the compiler writes a v_mov 0 in front of every DPP move) */
+    ALAC_DEV uint32_t pair_hi(uint32_t x) const { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xF5, 0xf, 0xf, true); } /* [1,1,3,3] */
+    ALAC_DEV int32_t pair_sum(int32_t x) const { return x + __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true); }            /* [1,0,3,2] */
     /* lane 1 takes lane 0's x, lane 0 takes `fresh` (q0m: all ones in lane 0) */
     ALAC_DEV uint32_t pair_from_below(uint32_t x, uint32_t fresh, uint32_t q0m) const {
-        return ALAC_BFI(q0m, fresh, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xA0, 0xf, 0xf, false)); /* [0,0,2,2] */
+        return ALAC_BFI(q0m, fresh, (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xA0, 0xf, 0xf, true)); /* [0,0,2,2] */
+    }
+    /* four lanes per packet: the same inside every group of four neighbouring lanes (quad_perm) */
+    template <int L>
+    ALAC_DEV uint32_t quad_from(uint32_t x) const { /* every lane takes lane L's x */
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, L * 0x55, 0xf, 0xf, true);
+    }
+    template <int D>
+    ALAC_DEV uint32_t quad_up(uint32_t x) const { /* lane q takes lane min(q + D, 3)'s x (the caller masks lanes without one) */
+        constexpr int c = D == 1 ? 0xF9 : D == 2 ? 0xFE : 0xFF; /* [1,2,3,3] [2,3,3,3] [3,3,3,3] */
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, c, 0xf, 0xf, true);
+    }
+    ALAC_DEV int32_t quad_sum(int32_t x) const {
+        const int32_t y = x + __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true); /* [1,0,3,2] */
+        return y + __builtin_amdgcn_mov_dpp(y, 0x4E, 0xf, 0xf, true);            /* [2,3,0,1] */
+    }
+    /* lane q takes lane q - 1's x, lane 0 takes `fresh` (q0m: all ones in lane 0) */
+    ALAC_DEV uint32_t quad_from_below(uint32_t x, uint32_t fresh, uint32_t q0m) const {
+        return ALAC_BFI(q0m, fresh, (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x90, 0xf, 0xf, true)); /* [0,0,1,2] */
     }
     /* chunk hand-over between the two waves of the workgroup: LDS traffic only, so outstanding global loads
      * (ring refills, U prefetch) and stores (U tile) are NOT waited for — __syncthreads() would drain them */

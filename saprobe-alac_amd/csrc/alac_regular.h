@@ -112,6 +112,18 @@
 /* 0 for x <= 0, else min(x, m): with m in {0, 1} "x is positive and m is set"; one v_med3_i32 on the GPU */
 #define ALAC_MED3_0(x, m) ((x) <= 0 ? 0 : ((x) < (m) ? (x) : (m)))
 #endif
+#ifndef ALAC_NOT_ADD
+/* ~a + c: one v_xad_u32 with the inline constant -1 on the GPU */
+#define ALAC_NOT_ADD(a, c) (~(uint32_t)(a) + (uint32_t)(c))
+#endif
+#ifndef ALAC_ALIGNBIT
+/* ({hi, lo} >> sh[4:0]) as 32 bits: v_alignbit_b32 on the GPU */
+#define ALAC_ALIGNBIT(hi, lo, sh) ((uint32_t)(((((uint64_t)(uint32_t)(hi)) << 32) | (uint32_t)(lo)) >> ((sh) & 31u)))
+#endif
+#ifndef ALAC_MULHI
+/* the high 32 bits of the 64-bit product: v_mul_hi_u32 on the GPU */
+#define ALAC_MULHI(a, b) ((uint32_t)(((uint64_t)(uint32_t)(a) * (uint64_t)(uint32_t)(b)) >> 32))
+#endif
 #ifndef ALAC_BFE
 /* (x >> off[4:0]) & ((1 << width[4:0]) - 1): v_bfe_u32 on the GPU */
 #define ALAC_BFE(x, off, width) ((((uint32_t)(x)) >> ((off) & 31u)) & ((1u << ((width) & 31u)) - 1u))
@@ -189,19 +201,27 @@ ALAC_DEV uint32_t classify_regular(const DevCfg& cfg, const uint8_t* pkt, uint32
 }
 
 /* ---- the lean path's bit reader: an LDS ring per lane, refilled ahead of time --------------------------------
- * w0,w1 hold stream dwords widx, widx+1 and w2 the next one, as in FastRd, but they are fed from a ring of
- * W::kRingDw (32) dwords in LDS (W::ring_*), never straight from HBM. The ring is topped up 32 bytes at a time on a
- * wave-uniform schedule (every 8th step): tick() first commits the block whose two global loads were issued 8 steps
- * earlier, then issues the next ones, and each packet byte is fetched from L2 exactly once. EIGHT steps, not four
- * (round 3): a lane enters a new 128-byte line every fourth block, so of a wave's 64 lanes some miss L2 at every
- * top-up, and four steps of the entropy wave are shorter than a trip to HBM: with 16-byte blocks every 4 steps the
- * wait at the top-up made the entropy step a quarter of the memory latency, whatever its instructions were (which is
- * why taking a third of them out changed nothing at first). A plain step consumes <= 26 bits (<= 32 with an escape
- * code), so 8 dwords per 8 steps sustain it (reseek() covers the slow path); start() prefills 24 dwords.
- * Positions handed to the reader are BIASED: stream bit p is position p + bias, bit p + bias of the dword array that
- * starts at `base` (the packet's start rounded down to a dword), so that no step adds the bias again.
+ * The stream lives in a ring of W::kRingDw (32) dwords per lane in LDS (W::ring_*), never read straight from HBM by a
+ * step. The ring is topped up 32 bytes at a time on a wave-uniform schedule (every 8th step): tick() first commits the
+ * block whose two global loads were issued 8 steps earlier, then issues the next ones, and each packet byte is fetched
+ * from L2 exactly once. EIGHT steps, not four (round 3): a lane enters a new 128-byte line every fourth block, so of a
+ * wave's 64 lanes some miss L2 at every top-up, and four steps of the entropy wave are shorter than a trip to HBM. A
+ * plain step consumes <= 26 bits (<= 41 with an inline escape code, which reseeks), so 8 dwords per 8 steps sustain it
+ * (reseek() covers the slow path); start() prefills 24 dwords.
+ * THE WINDOW (round 4). wa, wb are two consecutive stream dwords that hold the lane's next code: gol_step() asks for
+ * them (ONE ds_read2_b32: ring_read2) as soon as it knows where its code ends, and first looks at them in the NEXT step,
+ * behind that step's mean / k / zero-run arithmetic: the LDS round trip hides behind a dozen instructions that do not
+ * need it. Rounds 2-3 kept a cache of three dwords in registers and slid it with two v_bfi per step (+ the index
+ * arithmetic and the read of the third dword): ten instructions for the window where this form has four. Slot 32 of a
+ * lane's row repeats slot 0 (commit), so that the pair read at slot 31 needs no wrap.
+ * Positions are BIASED: stream bit p is bit p + bias of the dword array that starts at `base` (the packet's start
+ * rounded down to a dword), so that no step adds the bias again. The lane state (RegLane::pos) and start / reseek / tick
+ * hold such a position MINUS ONE, P: the pair is dwords P >> 5 and the next, the code starts (P & 31) + 1 = 1..32 bits
+ * into it, and its 32 bits are v_alignbit_b32(wa, wb, ~P) — a shift count of 0..31 in every case, where counting from the
+ * position itself would need the count 32 (or a 64-bit shift of a register PAIR, which a ds_read2_b32 delivers the
+ * wrong way round). window64 takes the position itself.
  * Dense blob (see Bits): blocks that lie wholly inside the packet are loaded as they are (one global_load_dwordx4);
- * a block that reaches past the packet's last byte takes tail4(): aligned dwords that hold at least one packet byte
+ * a block that reaches past the packet's last byte takes tail1(): aligned dwords that hold at least one packet byte
  * are fetched (they cannot leave the blob's pages), the neighbour's bytes in them are cleared, and dwords wholly
  * behind the packet are zeros without a fetch — the reference's zero pad (bitbuffer.go:33), as far out as anyone looks. */
 template <class W>
@@ -210,7 +230,7 @@ struct RingRd {
     uint32_t bias;        /* stream bit 0 is bit `bias` of base[0] */
     uint32_t end_b;       /* first byte, counted from base, that is not packet data */
     uint32_t full;        /* dwords [0, full) of base lie wholly inside the packet */
-    uint32_t w0, w1, w2, widx;
+    uint32_t wa, wb;      /* stream dwords P >> 5 and P >> 5 + 1 of the lane's position minus one (see above) */
     uint32_t fill;        /* ring holds dwords [fill - RING, fill); multiple of 8 */
     static constexpr uint32_t RING = W::kRingDw;
     static_assert(RING >= 32, "blocks of 8 dwords need a ring of 32");
@@ -224,7 +244,7 @@ struct RingRd {
         bias = mis * 8u;
         end_b = size ? mis + size : 0u; /* a lane without a packet keeps nothing of what it reads */
         full = end_b >> 2;
-        w0 = w1 = w2 = widx = fill = 0;
+        wa = wb = fill = 0;
         p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = 0;
         pend = false;
     }
@@ -255,14 +275,17 @@ struct RingRd {
         }
     }
     ALAC_DEV void commit(W& wv) {
-        wv.ring_write4(fill & (RING - 1u), __builtin_bswap32(p0), __builtin_bswap32(p1), __builtin_bswap32(p2),
-                       __builtin_bswap32(p3));
+        const uint32_t slot = fill & (RING - 1u);
+        const uint32_t d0 = __builtin_bswap32(p0);
+        wv.ring_write4(slot, d0, __builtin_bswap32(p1), __builtin_bswap32(p2), __builtin_bswap32(p3));
         wv.ring_write4((fill + 4u) & (RING - 1u), __builtin_bswap32(p4), __builtin_bswap32(p5), __builtin_bswap32(p6),
                        __builtin_bswap32(p7));
+        /* slot RING repeats slot 0 (a block that does not start the ring writes the spare slot behind it instead) */
+        wv.ring_write1(slot == 0u ? RING : RING + 1u, d0);
         fill += 8u;
         pend = false;
     }
-    /* channel start: synchronous prefill from the block holding the (biased) position */
+    /* channel start: synchronous prefill from the block holding the position (posb: minus one, as everywhere below) */
     ALAC_DEV void start(W& wv, uint32_t posb) {
         const uint32_t ni = posb >> 5;
         fill = ni & ~7u;
@@ -275,22 +298,16 @@ struct RingRd {
         reseek(wv, posb);
     }
     ALAC_DEV void reseek(W& wv, uint32_t posb) {
-        widx = posb >> 5;
+        const uint32_t ni = posb >> 5;
         /* a slow-path step (escape code + zero-run code) can eat more than one dword, more than tick() puts
          * back: top the ring up on the spot whenever it runs low: up to seven plain steps (<= 26 bits each) may follow
-         * before the next top-up, and the cache reads two dwords ahead. Positions are < 2^29 bits here (a live lane
-         * stays below max_pos + 66), so the loop ends. */
-        while (fill < widx + 12u) {
+         * before the next top-up, and a step reads the dword behind its position's. Positions are < 2^29 bits here (a
+         * live lane stays below max_pos + 66), so the loop ends. */
+        while (fill < ni + 12u) {
             if (!pend) load8(fill);
             commit(wv);
         }
-        w0 = wv.ring_read(widx & (RING - 1u));
-        w1 = wv.ring_read((widx + 1u) & (RING - 1u));
-        w2 = wv.ring_read((widx + 2u) & (RING - 1u));
-    }
-    ALAC_DEV uint32_t window(uint32_t posb) const {
-        const uint32_t r = posb & 31u;
-        return (uint32_t)(((((uint64_t)w0) << 32) | w1) << r >> 32);
+        wv.ring_read2(ni & (RING - 1u), wa, wb);
     }
     /* (cold) 64 stream bits from posb, MSB first, out of the LDS ring: what the slow path looks at. It used to ask the
      * stateless reader, i.e. global memory, a trip of a microsecond or two for every rare step; streams that are all
@@ -307,51 +324,56 @@ struct RingRd {
         const uint64_t hi = (a << 32) | b;
         return r ? (hi << r) | (c >> (32u - r)) : hi;
     }
-    /* the cache moves by 0 or 1 dword per step (the slow path reseeks); the move is a bit mask, not a compare;
-     * w2 is re-read from LDS every step */
-    ALAC_DEV void slide(W& wv, uint32_t posb) {
-        const uint32_t ni = posb >> 5;
-        const uint32_t cm = widx - ni; /* 0, or all ones when the position has entered the next dword */
-        w0 = ALAC_BFI(cm, w1, w0);
-        w1 = ALAC_BFI(cm, w2, w1);
-        widx = ni;
-        w2 = wv.ring_read((ni + 2u) & (RING - 1u));
-    }
-    /* every 8th step, wave-uniform */
-    ALAC_DEV void tick(W& wv) {
+    /* every 8th step, wave-uniform; posb: the lane's position */
+    ALAC_DEV void tick(W& wv, uint32_t posb) {
         if (pend) commit(wv);
-        if (fill + 8u <= widx + RING) {
+        if (fill + 8u <= (posb >> 5) + RING) {
             load8(fill);
             pend = true;
         }
     }
 };
 
-/* zrem of a lane that decodes nothing more: it has all its samples, has failed, or never had a packet. Far above any
- * real run length (<= 65535) and any number of steps that could count it down. */
+/* zero-run countdown of a lane that decodes nothing more: it has all its samples, has failed, or never had a packet. Far
+ * above any real run length (<= 65535) and any number of steps that could count it down. */
 constexpr uint32_t GOL_PARK = 0x40000000u;
 
 /* per-lane Golomb + reader state of one channel. pos and max_pos are biased (RingRd). */
 template <class W>
 struct RegLane {
     RingRd<W> rd;
-    uint32_t pos, mean, zmode, zrem, pb, max_pos;
+    uint32_t pos; /* biased position of the next code MINUS ONE (RingRd: THE WINDOW); max_pos: biased, not minus one */
+    uint32_t mean, zmode, pb, max_pos;
+    /* zeros this lane still has to queue from a zero run (golomb.go:232-240), MINUS ONE: -1 outside a run, so that the
+     * mask "not inside a run" is one arithmetic shift (gol_step) */
+    uint32_t zq;
+    uint32_t pbs; /* pb << 23: (pb * mean) >> 9 is the high half of mean * pbs (pb <= 127: lean_config) */
+    /* the HEAD of the next step: what it needs of pos, mean and zq before it looks at the window (gol_head) — worked out
+     * at the end of the step before, while the ring's answer is on its way: ~pos, 31 - k, (pb * mean) >> 9, the mask
+     * "not inside a zero run" */
+    uint32_t h_sh, h_ck, h_t9, h_norun;
     /* nonzero: the lane takes golomb_slow() in every step it decodes a code in. Set where the plain step's shortcuts
      * do not hold: within reach of the packet's end (overrun, golomb.go:168) or of the channel's last sample
      * (golomb.go:223: no zero run behind it; lock step: nothing at all behind it), and for the code that follows a
      * zero run (zmode = 1, golomb.go:206). Recomputed at every ring top-up (gol_near) and by the slow path. */
     uint32_t near;
     int32_t err;
-    ALAC_DEV uint32_t upos() const { return pos - rd.bias; } /* the stream position as the reference counts it */
+    ALAC_DEV uint32_t upos() const { return pos + 1u - rd.bias; } /* the stream position as the reference counts it */
+    ALAC_DEV void set_upos(uint32_t p) { pos = p + rd.bias - 1u; } /* p >= 1 */
+    ALAC_DEV void set_pb(uint32_t p) {
+        pb = p;
+        pbs = p << 23;
+    }
 };
 
 /* `near` for the steps up to the next top-up (at most 8 from step i on): a plain step takes at most 8 + 1 + 16 bits
- * (lean_config), one with an inline escape code (gol_step) at most 32: eight of them 256; the channel's last sample is
- * among the next eight when i + 8 >= ns_live */
-constexpr uint32_t GOL_TICK = 8; /* steps per ring top-up */
+ * (lean_config), one with an inline escape code (gol_step: any chanBits <= 32) at most 9 + 32: eight of them 328; the
+ * channel's last sample is among the next eight when i + 8 >= ns_live */
+constexpr uint32_t GOL_TICK = 8;  /* steps per ring top-up */
+constexpr uint32_t GOL_REACH = 41u * GOL_TICK; /* bits a lane can move between two looks at `near` */
 template <class W>
 ALAC_DEV uint32_t gol_near(const RegLane<W>& s, uint32_t i, uint32_t ns_live) {
-    return ALAC_SUBSAT(s.pos + 32u * GOL_TICK, s.max_pos) | ALAC_SUBSAT(i + GOL_TICK + 1u, ns_live) | s.zmode;
+    return ALAC_SUBSAT(s.pos + (GOL_REACH + 1u), s.max_pos) | ALAC_SUBSAT(i + GOL_TICK + 1u, ns_live) | s.zmode;
 }
 
 /* The rare part of DynDecomp (golomb.go:167-247) for one lane: the lane's last samples and everything behind them,
@@ -363,11 +385,11 @@ template <class W, class B>
 ALAC_DEV uint32_t golomb_slow(W& wv, const B& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb,
                               uint32_t chan_bits, uint32_t i, uint32_t ns, uint32_t& ns_live) {
     if (i >= ns_live) { /* nothing left to decode: park the lane (it looks like one inside an endless zero run) */
-        s.zrem = GOL_PARK;
+        s.zq = GOL_PARK - 1u;
         return 0u;
     }
     const uint32_t bias = s.rd.bias;
-    uint32_t pos = s.pos - bias, mean = s.mean, zmode = s.zmode, zrem = s.zrem;
+    uint32_t pos = s.upos(), mean = s.mean, zmode = s.zmode, zrem = s.zq + 1u;
     const uint32_t max_pos = s.max_pos - bias;
     int32_t err = 0;
     uint32_t ndq = 0;
@@ -431,47 +453,63 @@ ALAC_DEV uint32_t golomb_slow(W& wv, const B& bits, RegLane<W>& s, uint32_t size
         }
     }
     if (err == 0) {
-        s.pos = pos + bias;
+        s.set_upos(pos);
         s.mean = mean;
         s.zmode = zmode;
-        s.zrem = zrem;
+        s.zq = zrem - 1u;
         /* the steps up to the next top-up: at most seven (gol_near) */
-        s.near = ALAC_SUBSAT(pos + bias + 32u * GOL_TICK, s.max_pos) | ALAC_SUBSAT(i + GOL_TICK + 1u, ns_live) | zmode;
+        s.near = ALAC_SUBSAT(pos + bias + GOL_REACH, s.max_pos) | ALAC_SUBSAT(i + GOL_TICK + 1u, ns_live) | zmode;
         return ndq;
     }
     s.err = err;
-    s.zrem = GOL_PARK;
+    s.zq = GOL_PARK - 1u;
     ns_live = 0u;
     return 0u;
 }
 
+/* the head of a step from the lane state (RegLane::h_*): at a channel's start and behind the slow path; in the plain
+ * path every step works out the next one's (gol_step, block B) */
+template <class W>
+ALAC_DEV void gol_head(RegLane<W>& s, uint32_t c31kb) {
+    s.h_sh = ~s.pos;
+    s.h_norun = (uint32_t)((int32_t)s.zq >> 31);
+    s.h_t9 = ALAC_MULHI(s.mean, s.pbs); /* (pb * mean) >> 9, golomb.go:215 */
+    /* k = min(lg3a(mean >> 9), KB), golomb.go:172-174, as ck = 31 - k; c31kb = 31 - KB as a signed number */
+    s.h_ck = (uint32_t)imax((int32_t)ALAC_FFBH((s.mean >> 9) + 3u), (int32_t)c31kb);
+}
+
 /*
  * One residual (DynDecomp, golomb.go:167-247), the form the entropy wave of alac_duo.h and the scan run. Every
- * instruction of the step costs the same (a lone wave issues a dependent one every 8.3 cycles, two waves on a SIMD
- * one every 4.2 between them: profiles/microbench), so the step is written for the fewest of them: plain integer
- * arithmetic on bit masks, no select, no sign folding (the predictor wave does that), one branch for everything rare
- * (golomb_slow). What lets it be short:
+ * instruction of the step costs the same, and one that needs the result of the instruction right before it costs a lone
+ * wave 8.3 cycles instead of 4.8 (profiles/microbench), so the step is written for the fewest of them AND in an order in
+ * which no instruction reads its predecessor's result: plain integer arithmetic on bit masks, no select, no sign folding
+ * (the predictor wave does that), one branch for everything rare (golomb_slow). What lets it be short:
  *  - k is kept as 31 - k (v_ffbh gives it that way round) and the code's value is one bit-field extract;
- *  - a lane inside a zero run (zrem != 0; a parked lane is one too) queues a 0 and moves nothing: its n is masked, and
- *    with n = 0 and mean = 0 (where a run leaves it, golomb.go:245) the mean update yields 0 again by itself;
+ *  - the 64 stream bits the code lies in were asked for by the step before (RingRd: THE WINDOW);
+ *  - (pb * mean) >> 9 is one v_mul_hi_u32 against pb << 23;
+ *  - a lane inside a zero run (zq >= 0; a parked lane is one too) queues a 0 and moves nothing: its n is masked, and with
+ *    n = 0 and mean = 0 (where a run leaves it, golomb.go:245) the mean update yields 0 again by itself; the countdown is
+ *    kept minus one, so that the mask is its sign and the step down (not below -1) one v_xad_u32;
  *  - overrun, the end of the lane's samples and zmode are not tested here at all: `near` sends the lane to the slow
  *    path while any of them is within reach (RegLane).
+ * TWO BLOCKS (round 4). A: window -> prefix -> value -> new position -> the ring slot of the next window; the read of
+ * that slot (the caller's W::ring_read2_at, an instruction of the compiler's own, which therefore also places the wait
+ * for it: right in front of the next step's block A); B: the mean, the rare-case flags and the next step's HEAD (RegLane)
+ * — a dozen instructions between the read and the first look at its answer. On the GPU each block is ONE asm statement
+ * (alac_gpu.h: ALAC_GOL_BLOCK_A / _B, the statements below instruction for instruction): the compiler keeps neither the
+ * order of single statements nor asm statements apart from their readers without s_nop; a block it can
+ * only take whole. The C++ form is what tests/host_sim runs and what ALAC_GOL_ASM 0 builds.
  * Returns n + zmode (0 inside a run).
  */
+#ifndef ALAC_GOL_ASM
+#define ALAC_GOL_ASM 0
+#endif
 template <bool ESC, class W, class B>
 ALAC_DEV uint32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, uint32_t kb, uint32_t wb, uint32_t c31kb,
                            uint32_t chan_bits, uint32_t i, uint32_t ns, uint32_t& ns_live) {
-    /* ISSUE ORDER. The build keeps source order (csrc/Makefile), a wave issues in order, and an instruction whose
-     * operand comes from the instruction right before it waits 8.3 cycles instead of 4.8 (profiles/microbench/valu_more,
-     * chains=1): a lone wave running this step as one dependent chain needs twice the time of one that always has an
-     * independent instruction at hand. The step is three chains — P: position -> window -> prefix -> value -> position;
-     * M: mean -> k, and mean * pb; Z: the zero-run countdown — and the statements below alternate between them so that
-     * (almost) nothing uses the result of its predecessor. The slide of the window cache is done here too, before the
-     * rare cases are known: the slow path reseeks anyway. ESC: inside the rare branch an escape code that is nothing
-     * but that takes a few instructions instead of golomb_slow. */
-    const uint32_t o_pos = s.pos, o_mean = s.mean, o_zrem = s.zrem;
+    const uint32_t o_pos = s.pos, o_mean = s.mean, o_zq = s.zq;
     RingRd<W>& rd = s.rd;
-    const uint32_t o_w0 = rd.w0, o_w1 = rd.w1, o_w2 = rd.w2; /* the window cache before the step (rare path only) */
+    const uint32_t o_wa = rd.wa, o_wb = rd.wb; /* stream dwords o_pos >> 5 and the next (o_pos: minus one) */
 #ifdef ALAC_PAD_A /* experiment: what an instruction more in the entropy step costs */
     {
         uint32_t pad_ = i;
@@ -479,69 +517,85 @@ ALAC_DEV uint32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, u
         for (int t_ = 0; t_ < ALAC_PAD_A; ++t_) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad_));
     }
 #endif
-    const uint32_t r = o_pos & 31u;                                                     /* P */
-    const uint32_t x9 = o_mean >> 9;                                                    /* M */
-    const uint32_t w = (uint32_t)(((((uint64_t)rd.w0) << 32) | rd.w1) << r >> 32);      /* P: the 32 stream bits at pos */
-    const uint32_t x3 = x9 + 3u;                                                        /* M */
-    const uint32_t nw = ~w;                                                             /* P */
-    const uint32_t c = ALAC_FFBH(x3);                                                   /* M: 31 - lg3a(mean >> 9) */
-    const uint32_t pre = ALAC_FFBH(nw); /* P: leading ones; all 32 read as 2^32 - 1: rare either way */
-    /* k = min(lg3a(mean >> 9), KB), golomb.go:172-174, as ck = 31 - k; c31kb = 31 - KB as a signed number */
-    const uint32_t ck = (uint32_t)imax((int32_t)c, (int32_t)c31kb);                     /* M */
-    const uint32_t z1 = o_zrem - 1u;                                                    /* Z */
-    const uint32_t k = 31u - ck; /* 1..16 */                                            /* M */
-    const uint32_t off = ck - pre;                                                      /* P */
-    const uint32_t norun = (uint32_t)((int32_t)z1 >> 31); /* zrem == 0 (zrem < 2^31) */ /* Z */
-    const uint32_t v = ALAC_BFE(w, off, k); /* the k bits behind the prefix and its 0 (golomb.go:192) */
-    const uint32_t pm = s.pb * o_mean;                                                  /* M */
-    const uint32_t zrem2 = ALAC_SUBSAT(o_zrem, 1u);                                     /* Z */
-    const uint32_t vm1 = ALAC_SUBSAT(v, 1u); /* v >= 2: value v - 1 and k bits; else 0 and k - 1 bits */
-    const uint32_t t9 = pm >> 9;                                                        /* M */
-    const uint32_t pk = pre << k;                                                       /* P */
-    const uint32_t c2 = umin(vm1, 1u);
-    const uint32_t mt = o_mean - t9;                                                    /* M */
-    uint32_t n = pk + vm1 - pre;             /* pre * (2^k - 1) + ... */
-    const uint32_t cons = pre + k + c2;      /* prefix + 1, then k bits (v >= 2) or k - 1 */
-    const uint32_t esc = ALAC_SUBSAT(pre, 8u); /* nine ones: an escape code (golomb.go:184) */
-    n &= norun;
-    const uint32_t cm = cons & norun;
-    const uint32_t mean2 = ALAC_MULU24(s.pb, n) + mt; /* golomb.go:215; n <= 0xffff or rare */
-    const uint32_t pos2 = o_pos + cm;
-    const uint32_t nhi = (n >> 16) | esc;
-    const uint32_t ni = pos2 >> 5;
-    const uint32_t zs = ALAC_SUBSAT(128u, mean2);
-    const uint32_t cmk = rd.widx - ni; /* 0, or all ones when the position has entered the next dword */
-    /* rare cases, as nonzero-means-true flags: escape code (golomb.go:184), n > 0xffff (:216), near (RegLane), start of
-     * a zero run (:223: mean * 4 < 512; mean2 < 2^26, the shift cannot wrap) */
-    const uint32_t fl = nhi | s.near | zs;
-    const uint32_t nw0 = ALAC_BFI(cmk, rd.w1, rd.w0);
-    const uint32_t rare = fl & norun;
-    const uint32_t nw1 = ALAC_BFI(cmk, rd.w2, rd.w1);
+    uint32_t n, esc, mt, pos2, aoff, zq2, mean2, nhi;
+    uint32_t rare, sh2, ck2, t92, norun2;
+#if ALAC_GOL_ASM
+    ALAC_GOL_BLOCK_A(o_wa, o_wb, s.h_sh, s.h_ck, s.h_t9, s.h_norun, o_pos, o_mean, o_zq, s.pb, n, esc, mt, pos2, aoff, zq2, mean2, nhi);
+#else
+    {
+        const uint32_t ck = s.h_ck, norun = s.h_norun;
+        const uint32_t w = ALAC_ALIGNBIT(o_wa, o_wb, s.h_sh);   /* the 32 stream bits at the position */
+        const uint32_t k = 31u - ck; /* 1..16 */
+        const uint32_t nw = ~w;
+        mt = o_mean - s.h_t9;
+        const uint32_t pre = ALAC_FFBH(nw); /* leading ones; all 32 read as 2^32 - 1: rare either way */
+        zq2 = ALAC_NOT_ADD(norun, o_zq);    /* one down inside a run, -1 stays */
+        const uint32_t off = ck - pre;
+        esc = ALAC_SUBSAT(pre, 8u);         /* nine ones: an escape code (golomb.go:184) */
+        const uint32_t v = ALAC_BFE(w, off, k); /* the k bits behind the prefix and its 0 (golomb.go:192) */
+        uint32_t pk = pre << k;
+        const uint32_t c2 = v > 1u ? 1u : 0u; /* v >= 2: value v - 1 and k bits; else 0 and k - 1 bits */
+        const uint32_t vm1 = ALAC_SUBSAT(v, 1u);
+        pk -= pre;                          /* pre * (2^k - 1) */
+        const uint32_t cons = pre + k + c2; /* prefix + 1, then k bits (v >= 2) or k - 1 */
+        n = pk + vm1;
+        const uint32_t cm = cons & norun;
+        n &= norun;
+        pos2 = o_pos + cm;
+        mean2 = ALAC_MULU24(s.pb, n) + mt;  /* golomb.go:215; n <= 0xffff or rare */
+        aoff = pos2 >> 3;
+        nhi = n >> 16;
+        aoff &= 4u * (RingRd<W>::RING - 1u); /* byte offset of ring slot (pos2 >> 5) & 31 in the lane's row */
+    }
+#endif
+    /* the next step's window: asked for now, looked at in the next step's block A */
+    wv.ring_read2_at(aoff, rd.wa, rd.wb);
+#if ALAC_GOL_ASM
+    ALAC_GOL_BLOCK_B(mean2, nhi, esc, pos2, zq2, s.h_norun, s.near, s.pbs, c31kb, rare, sh2, ck2, t92, norun2);
+#else
+    {
+        /* rare cases, as nonzero-means-true flags: escape code (golomb.go:184), n > 0xffff (:216), near (RegLane), start
+         * of a zero run (:223: mean * 4 < 512; mean2 < 2^26, the shift cannot wrap) */
+        const uint32_t zs = ALAC_SUBSAT(128u, mean2);
+        uint32_t x = mean2 >> 9;
+        sh2 = ~pos2;
+        const uint32_t fl = esc | nhi | zs;
+        t92 = ALAC_MULHI(mean2, s.pbs);
+        x += 3u;
+        norun2 = (uint32_t)((int32_t)zq2 >> 31);
+        x = ALAC_FFBH(x);
+        rare = (fl | s.near) & s.h_norun;
+        ck2 = (uint32_t)imax((int32_t)x, (int32_t)c31kb);
+    }
+#endif
     s.pos = pos2;
     s.mean = mean2;
-    s.zrem = zrem2;
-    rd.w0 = nw0;
-    rd.w1 = nw1;
-    rd.widx = ni;
-    rd.w2 = wv.ring_read((ni + 2u) & (RingRd<W>::RING - 1u));
+    s.zq = zq2;
+    s.h_sh = sh2;
+    s.h_ck = ck2;
+    s.h_t9 = t92;
+    s.h_norun = norun2;
     uint32_t ndq = n;
     /* ONE wave-uniform branch around everything rare, and the divergent ones inside it: the plain path holds one compare
      * and one scalar branch, and whatever the compiler needs to merge the lanes' state (copies, saved exec masks) stays
      * in there */
     if (ALAC_UNLIKELY(wv.any(rare != 0u))) {
         if (rare != 0u) {
-            /* ESC: the two rare cases that need no more than the window cache held before this step (96 stream bits from
-             * the position's dword on), for a lane that is not within reach of the packet's end (near), so that nothing
-             * of the reference's bounds can fail. (1) An escape code (one sample in two thousand of music has one, i.e.
-             * one step in thirty of a wave of 64; every other sample of a 24-bit stream without shift bytes): the
-             * value is the chan_bits <= 32 bits behind the nine ones (golomb.go:184-186, getStreamBits :86-108).
-             * (2) n > 0xffff: the mean is clamped (golomb.go:216-218). Everything else, and a zero run behind either
-             * (mean * 4 < 512), takes golomb_slow from the lane's old state. */
+            /* ESC: the two rare cases that need no more than the 96 stream bits from the position's dword on, for a lane
+             * that is not within reach of the packet's end (near), so that nothing of the reference's bounds can fail.
+             * (1) An escape code (one sample in two thousand of music has one, i.e. one step in thirty of a wave of 64;
+             * every other sample of a 24-bit stream without shift bytes): the value is the chan_bits <= 32 bits behind
+             * the nine ones (golomb.go:184-186, getStreamBits :86-108). (2) n > 0xffff: the mean is clamped
+             * (golomb.go:216-218). Everything else, and a zero run behind either (mean * 4 < 512), takes golomb_slow from
+             * the lane's old state. */
             bool done = false;
             if (ESC && s.near == 0u) {
                 if (esc != 0u && chan_bits <= 32u && chan_bits != 0u) {
-                    const uint64_t hi = (((uint64_t)o_w0) << 32) | o_w1;
-                    const uint64_t w64 = r ? (hi << r) | ((uint64_t)o_w2 >> (32u - r)) : hi; /* 64 stream bits from the position */
+                    const uint64_t hi = (((uint64_t)o_wa) << 32) | o_wb;
+                    const uint32_t o_wc = wv.ring_read(((o_pos >> 5) + 2u) & (RingRd<W>::RING - 1u));
+                    const uint32_t r1 = (o_pos & 31u) + 1u; /* 1..32: where the code starts in the pair */
+                    const uint64_t w64 = r1 < 32u ? (hi << r1) | ((uint64_t)o_wc >> (32u - r1))
+                                                  : ((((uint64_t)o_wb) << 32) | o_wc); /* 64 stream bits from the position */
                     const uint32_t n2 = (uint32_t)((w64 << 9) >> (64u - chan_bits));
                     const uint32_t m2 = n2 > 0xffffu ? 0xffffu : s.pb * n2 + mt;
                     if (m2 >= 128u) {
@@ -559,10 +613,11 @@ ALAC_DEV uint32_t gol_step(W& wv, const B& bits, RegLane<W>& s, uint32_t size, u
             if (!done) {
                 s.pos = o_pos;
                 s.mean = o_mean;
-                s.zrem = o_zrem;
+                s.zq = o_zq;
                 ndq = golomb_slow(wv, bits, s, size, kb, wb, chan_bits, i, ns, ns_live);
             }
-            rd.reseek(wv, s.pos); /* the window cache afresh */
+            rd.reseek(wv, s.pos); /* the window afresh */
+            gol_head(s, c31kb);   /* and the head of the lane's next step */
         }
     }
     return ndq;
@@ -769,12 +824,12 @@ ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_
     s.rd.init(pkt, size);
     s.err = 0;
     s.max_pos = size * 8u + s.rd.bias;
-    s.pos = (go ? pos : 0u) + s.rd.bias;
+    s.set_upos(go ? pos : 1u);
     s.mean = cfg.mb;
     s.zmode = 0;
-    s.zrem = 0;
+    s.zq = 0xffffffffu;
     s.near = 0;
-    s.pb = pb_local;
+    s.set_pb(pb_local);
     const uint32_t my_ns = go ? ns : 0u;
     const uint32_t n_it = wv.max_u32(my_ns);
     uint32_t kb = cfg.kb;
@@ -782,6 +837,7 @@ ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_
     const uint32_t wb = go_shl(1u, kb) - 1u; /* golomb.go:60 */
     const uint32_t c31kb = 31u - kb;
     s.rd.start(wv, s.pos);
+    gol_head(s, c31kb);
     uint32_t ns_live = my_ns;
     const bool keep = res_row != nullptr;
     /* the four residuals of a group are stored at the top of the NEXT group, right behind the ring's top-up: vector
@@ -798,20 +854,20 @@ ALAC_DEV void scan_channel(W& wv, const DevCfg& cfg, const B& bits, const uint8_
         i += 4u;
     };
     while (i + GOL_TICK <= n_it) { /* eight steps per ring top-up */
-        s.rd.tick(wv);
+        s.rd.tick(wv, s.pos);
         s.near = gol_near(s, i, ns_live);
 #pragma nounroll
         for (uint32_t h = 0; h < GOL_TICK; h += 4u) four();
     }
     if (i + 4u <= n_it) {
-        s.rd.tick(wv);
+        s.rd.tick(wv, s.pos);
         s.near = gol_near(s, i, ns_live);
         four();
     }
     if (keep && go && i != 0u) ALAC_STORE4(res_row + (i - 4u), (int32_t)h0, (int32_t)h1, (int32_t)h2, (int32_t)h3);
     for (; i < n_it; ++i) {
         if ((i & (GOL_TICK - 1u)) == 0) {
-            s.rd.tick(wv);
+            s.rd.tick(wv, s.pos);
             s.near = gol_near(s, i, ns_live);
         }
         const uint32_t d = gol_step<true>(wv, bits, s, size, kb, wb, c31kb, chan_bits, i, my_ns, ns_live);

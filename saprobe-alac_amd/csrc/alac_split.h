@@ -53,11 +53,11 @@ ALAC_DEV void decode_channel_task(W& wv, const DevCfg& cfg, uint32_t key, bool l
     const uint32_t h = bits.get(d.hdr_pos, 16);
     const uint32_t mode = live ? (h >> 12) : 0u;
     const uint32_t den_shift = (h >> 8) & 0xfu;
-    s.pb = (cfg.pb * ((h >> 5) & 7u)) / 4u; /* decoder.go:299 */
+    s.set_pb((cfg.pb * ((h >> 5) & 7u)) / 4u); /* decoder.go:299 */
     s.mean = cfg.mb;
     s.zmode = 0;
-    s.zrem = 0;
-    s.pos = (live ? d.ent_pos : 0u) + s.rd.bias;
+    s.zq = 0xffffffffu;
+    s.set_upos(live ? d.ent_pos : 1u);
     const uint32_t ns = live ? d.ns : 0u;
     const uint32_t chan_bits = live ? ((d.info >> CD_CHANBITS_SHIFT) & 63u) : 16u;
     const uint32_t n_it = wv.max_u32(ns);

@@ -59,6 +59,7 @@ ALAC_DEV uint32_t layout_offset(uint32_t num_chan, uint32_t chan_idx) {
 
 /* ---- Go shift semantics (SURVEY.md §8a trap 1): counts >= 32 give 0 / sign fill ----------------------- */
 ALAC_DEV uint32_t go_shl(uint32_t x, uint32_t n) { return n >= 32 ? 0u : x << n; }
+ALAC_DEV uint32_t go_shr(uint32_t x, uint32_t n) { return n >= 32 ? 0u : x >> n; }
 /* (x << chanShift) >> chanShift, predictor.go:68,78,130 */
 ALAC_DEV int32_t sext_cs(int32_t x, uint32_t cs) { return cs >= 32 ? 0 : (int32_t)((uint32_t)x << cs) >> cs; }
 /* signOfInt, predictor.go:35-39 */
@@ -522,7 +523,12 @@ ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t*
                             uint32_t m = mean >> 9;
                             const uint32_t k = umin(31u - clz32(m + 3u), cfg.kb);
                             m = go_shl(1u, k) - 1u;
-                            const uint32_t w = rd.window(pos);
+                            /* The reference's window is read32bit(bitPos >> 3) << (bitPos & 7) (golomb.go:179-180): 32 bits
+                             * from the BYTE the position lies in, so its low bitPos & 7 bits are zeros, not stream bits. A
+                             * prefix and k bits reach in there once k > 16, which takes KB > 16 and a mean above 2^25: an
+                             * effective pb above 127 (cookie PB > 73), where pb * mean wraps and the mean no longer
+                             * contracts. (Found by the randomized sweep with PB 255, KB 32, round 4.) */
+                            const uint32_t w = rd.window(pos) & (0xffffffffu << (pos & 7u));
                             uint32_t n = clz32(~w);
                             if (n >= 9) {
                                 /* escape code: getStreamBits(bitPos+9, maxSize), golomb.go:184-186,86-108 */
@@ -566,14 +572,16 @@ ALAC_DEV int32_t decode_wave(W& wv, const DevCfg& cfg, bool live, const uint8_t*
                                         err = ST_MALFORMED;
                                         err_chan = c;
                                     } else {
-                                        const uint32_t wz = rd.window(pos);
+                                        const uint32_t wz = rd.window(pos) & (0xffffffffu << (pos & 7u)); /* as above (golomb.go:115-116) */
                                         const uint32_t pre = clz32(~wz);
                                         uint32_t rl;
                                         if (pre >= 9) {
                                             rl = (wz << 9) >> 16;
                                             pos += 25u;
                                         } else {
-                                            const uint32_t val = kz == 0 ? 0u : (wz << (pre + 1u)) >> (32u - kz);
+                                            /* kz > 32 (the mean has passed 2^30 and mean << 2 wrapped: pb > 127 only): Go's
+                                             * shift by 32 - kz, a huge uint32, gives 0 (golomb.go:133) */
+                                            const uint32_t val = kz == 0 ? 0u : go_shr(wz << (pre + 1u), 32u - kz);
                                             pos += pre + 1u + kz;
                                             if (val < 2) {
                                                 rl = pre * mz;

@@ -301,7 +301,7 @@ def build3():
 
 
 def build4():
-    """K20..K22 (round 4): cookie bytes PB and MB other than 40 / 10 (config.go:72-73), the mean trajectories worked on
+    """K20..K23 (round 4): cookie bytes PB and MB (K23: KB too) other than 40 / 10 (/ 14) (config.go:72-73), the mean trajectories worked on
     paper from golomb.go:172-246 with pb = PB * pbFactor / 4 (decoder.go:296-299). Derivations: kat_derivation.md, third
     part. All three are 16- / 20-bit SCEs with numActive 0 (the samples are the residuals, predictor.go:53-60) and
     FrameLength 40, so that the GPU library sorts them under a regular key (alac_regular.h: classify_regular)."""
@@ -365,6 +365,26 @@ def build4():
     vals = [-32768, -1, -16383, 0, 32768, 0, 0, 0, 0] + [0] * 31
     kats.append({"name": "K22 PB 255 (pb 446: uint32 wrap), MB 1, 20-bit", "frame_length": 40, "bit_depth": 20,
                  "num_channels": 1, "pb": 255, "mb": 1, "packet": bw.hex(), "pcm": le([v << 4 for v in vals], 3)})
+
+    # ---- K23: the reference's 32-bit window has 32 - (bitPos & 7) stream bits (golomb.go:179-180): a code of 9 + 17 bits at
+    #      bit offset 7 ends in the zero fill. KB 32 lets k reach 17 once the mean has passed 2^26 (pb 446: no contraction)
+    bw = BitWriter()
+    elem_header(bw, 0)
+    bw.put(0, 8).put(0, 8)
+    chan_header(bw, 0, 0, 7, [])
+    bw.raw("111111111").put(0xFFFF, 20)      # s0 (bit 55): k = 1, escape code, n = 65535 -> -32768; mean 29 228 611
+    bw.raw("110").put(2, 15)                 # s1 (bit 84): k = 15: pre 2, v 2 -> n = 65535; mean 58 162 185
+    bw.raw("10").put(0, 15)                  # s2 (bit 102): k = 16: pre 1, v < 2 -> n = 65535; mean 87 057 728
+    bw.raw("111111110").put(5, 17)           # s3 (bit 119, offset 7): k = 17: pre 8; the stream says v = 5, the window 4
+    bw.raw("0").put(0, 6)                    # s4: k = 7: n = 0; mean 8448
+    bw.raw("0").put(0, 3)                    # s5: k = 4: n = 0; mean 1089
+    bw.raw("0 0")                            # s6: k = 2: n = 0; mean 141
+    bw.raw("0")                              # s7: k = 1: n = 0; mean 19 -> zero run, k32 = 3, mz = 7
+    bw.raw("11110 101")                      # run of 4 * 7 + 5 - 1 = 32: s8..s39
+    bw.put(7, 3)
+    vals = [-32768, -32768, -32768, -524286, 0, 0, 0, 0] + [0] * 32
+    kats.append({"name": "K23 KB 32, PB 255: a code that ends in the window's zero fill", "frame_length": 40, "bit_depth": 20,
+                 "num_channels": 1, "pb": 255, "mb": 1, "kb": 32, "packet": bw.hex(), "pcm": le([v << 4 for v in vals], 3)})
     return kats
 
 

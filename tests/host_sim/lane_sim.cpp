@@ -64,7 +64,7 @@ struct HostWave {
     }
     void st_step() {}
     uint32_t st_finish() { return st_cnt; }
-    uint32_t ring[32] = {0};
+    uint32_t ring[36] = {0}; /* kRingStride: slot 32 repeats slot 0, slot 33 is spare (RingRd::commit) */
     void ring_write4(uint32_t slot, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
         ring[slot] = a;
         ring[slot + 1] = b;
@@ -72,6 +72,12 @@ struct HostWave {
         ring[slot + 3] = d;
     }
     uint32_t ring_read(uint32_t slot) const { return ring[slot]; }
+    void ring_read2(uint32_t slot, uint32_t& a, uint32_t& b) const {
+        a = ring[slot];
+        b = ring[slot + 1];
+    }
+    void ring_read2_at(uint32_t byte_off, uint32_t& a, uint32_t& b) const { ring_read2(byte_off >> 2, a, b); }
+    void ring_write1(uint32_t slot, uint32_t v) { ring[slot] = v; }
     /* residual queue of alac_duo.h: one lane, both roles played by the same caller, so the barriers are no-ops */
     int32_t rq[2][2 * alac::DUO_CHUNK] = {{0}};
     void rq_write(uint32_t buf, uint32_t j, int32_t v) { rq[buf][j] = v; }

@@ -35,7 +35,7 @@ def test_goref_reproduces_the_hand_derived_kats():
         k = json.load(open(os.path.join(HERE, "golden", name)))
         c = k["config_common"]
         for v in k["vectors"]:
-            cfg = goref.PacketConfig(v["frame_length"], v["bit_depth"], v["num_channels"], v.get("pb", c.get("pb")), v["mb"], c["kb"],
+            cfg = goref.PacketConfig(v["frame_length"], v["bit_depth"], v["num_channels"], v.get("pb", c.get("pb")), v["mb"], v.get("kb", c["kb"]),
                                      c["max_run"])
             pcm, frames, st = goref.decode_packet(cfg, bytes.fromhex(v["packet"]))
             assert st == 0 and frames == v.get("frames", v["frame_length"]), v["name"]

@@ -35,14 +35,14 @@ def test_known_answer_packets_on_gpu(pkg):
 
 
 def test_hand_derived_predictor_and_matrix_packets_on_gpu(pkg):
-    """K5..K13, K14..K19 and K20..K22 (other cookie bytes: PB 20 / 73 / 255, MB 0 / 255 / 1; tests/golden/kat_derivation.md)
+    """K5..K13, K14..K19 and K20..K23 (other cookie bytes: PB 20 / 73 / 255, MB 0 / 255 / 1, KB 32; tests/golden/kat_derivation.md)
     through DecodePacket on the GPU."""
     k = json.load(open(os.path.join(HERE, "golden", "kat2.json")))
     c = k["config_common"]
     more = [json.load(open(os.path.join(HERE, "golden", n)))["vectors"] for n in ("kat3.json", "kat4.json")]
     for v in k["vectors"] + more[0] + more[1]:
         cfg = pkg.PacketConfig(FrameLength=v["frame_length"], BitDepth=v["bit_depth"], NumChannels=v["num_channels"],
-                               PB=v.get("pb", c["pb"]), MB=v["mb"], KB=c["kb"], MaxRun=c["max_run"])
+                               PB=v.get("pb", c["pb"]), MB=v["mb"], KB=v.get("kb", c["kb"]), MaxRun=c["max_run"])
         with pkg.NewPacketDecoder(cfg) as dec:
             pcm = dec.DecodePacket(bytes.fromhex(v["packet"]))
             assert pcm.hex().upper() == v["pcm"].upper(), v["name"]

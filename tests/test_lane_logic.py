@@ -158,7 +158,7 @@ def test_wide_channels_take_the_wave_pair(oracle, synth, lane_sim, helpers, dept
 
 
 def test_lane_logic_reproduces_the_hand_derived_packets(oracle, lane_sim):
-    """K1..K22 (tests/golden/kat*.json, derived on paper from the reference source) through the kernel's decode logic
+    """K1..K23 (tests/golden/kat*.json, derived on paper from the reference source) through the kernel's decode logic
     as built for the host: every routing the GPU library can take for them."""
     import json
     import os
@@ -168,7 +168,7 @@ def test_lane_logic_reproduces_the_hand_derived_packets(oracle, lane_sim):
         c = k["config_common"]
         for v in k["vectors"]:
             depth = v.get("bit_depth", c.get("bit_depth"))
-            cfg = oracle.make_config(v["frame_length"], depth, v["num_channels"], v.get("pb", c.get("pb")), v.get("mb", c.get("mb")), c["kb"],
+            cfg = oracle.make_config(v["frame_length"], depth, v["num_channels"], v.get("pb", c.get("pb")), v.get("mb", c.get("mb")), v.get("kb", c["kb"]),
                                      c["max_run"])
             pkt = np.frombuffer(bytes.fromhex(v["packet"].replace(" ", "")), np.uint8)
             want = bytes.fromhex(v["pcm"].replace(" ", ""))

@@ -75,10 +75,11 @@ def _kat4():
 
 @pytest.mark.parametrize("vec", _kat4()["vectors"], ids=lambda v: v["name"].split()[0])
 def test_hand_derived_packets_with_other_cookie_bytes(oracle, vec):
-    """K20..K22 (tests/golden/kat_derivation.md, third part): PB 20 / 73 / 255 with pbFactor 6 / 7 / 7 (pb 30, 127 and 446:
-    pb * mean wraps in uint32, golomb.go:215) and MB 0 / 255 / 1 as the first mean (config.go:72-73, decoder.go:296-299)."""
+    """K20..K23 (tests/golden/kat_derivation.md, third part): PB 20 / 73 / 255 with pbFactor 6 / 7 / 7 (pb 30, 127 and 446:
+    pb * mean wraps in uint32, golomb.go:215) and MB 0 / 255 / 1 as the first mean (config.go:72-73, decoder.go:296-299);
+    K23: KB 32 and a code of 9 + 17 bits that ends in the zero fill of the reference's 32-bit window (golomb.go:179-180)."""
     c = _kat4()["config_common"]
-    cfg = oracle.make_config(vec["frame_length"], vec["bit_depth"], vec["num_channels"], vec["pb"], vec["mb"], c["kb"],
+    cfg = oracle.make_config(vec["frame_length"], vec["bit_depth"], vec["num_channels"], vec["pb"], vec["mb"], vec.get("kb", c["kb"]),
                              c["max_run"])
     st, frames, pcm = oracle.decode_packet(cfg, bytes.fromhex(vec["packet"]))
     assert st == 0

@@ -72,6 +72,11 @@ for r in range(rounds):
         print("round %d: depth %d ch %d fl %d prof %d n %d ppw %r kb %d pb %d mb %d lanes_min %r what %d" % (r, depth, ch, fl, prof, len(offs), ppw, kb, pb, mb, lm, what), flush=True)
     if DRY:
         rng.integers(0, 4)
+        if os.environ.get("ALACGPU_FUZZ_DUMP") == str(r):  # this round's batch and the oracle's answer, for tests/host_sim or a debugger
+            np.savez(os.environ.get("ALACGPU_FUZZ_DUMP_TO", "/tmp/fuzz_round.npz"), blob=blob, offs=offs, sizes=sizes, out=ref[0], frames=ref[1], status=ref[2],
+                     cfg=np.array([fl, depth, ch, pb, mb, kb]))
+            print("dumped round %d" % r)
+            sys.exit(0)
         continue
     c = pkg.PacketConfig(FrameLength=fl, BitDepth=depth, NumChannels=ch, PB=cfg.pb, MB=cfg.mb, KB=cfg.kb,
                          MaxRun=cfg.max_run, SampleRate=cfg.sample_rate)
