@@ -34,7 +34,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--packets", type=int, default=65536, help="packets per GPU (weak scaling)")
+    ap.add_argument("--packets", type=int, default=65536, help="packets per GPU (weak scaling); BASELINE config e "
+                    "(262 144 packets over 8 GPUs) is --gpus 8 --packets 32768")
     ap.add_argument("--depth", type=int, default=16)
     ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--frame-length", type=int, default=4096)
@@ -48,16 +49,22 @@ def parse():
     return ap.parse_args()
 
 
-def pair_kernel(depth, ch, packets):
-    """Which of the pair kernels decodes a batch of regular packets (k_decode_body.inc: three_waves / pair_gated decide
-    on the device from the number of 64-packet wave slots; 256 CUs assumed here, for the name only)."""
-    slots = (packets + 63) // 64
-    name = {16: "16", 20: "24", 24: "24", 32: "32"}[depth]
-    if slots <= 1024:
-        return "alac_decode_%sq (entropy, predictor and writer wave per 64 packets; two predictor waves for long predictors in small batches)" % name
-    if depth == 16:
-        return "alac_decode_16 / alac_decode_16g (wave pairs; the gated twin between the multiples of 4 x CUs slots)"
-    return "alac_decode_%s (wave pairs)" % name
+def kernels_of(dispatch):
+    """The kernels of the last decode as the DEVICE dispatched them (alacgpu_last_dispatch reads the launch plan back):
+    dominant kernel first."""
+    parts = []
+    if dispatch["narrow_slots"]:
+        lanes = dispatch["lanes_per_packet"]
+        parts.append("%s (%d narrow regular wave slots of %d packets%s)" % (
+            dispatch["narrow_kernel"], dispatch["narrow_slots"], dispatch["packets_per_slot"],
+            "; long predictors on %d lanes per packet" % lanes if lanes else ""))
+    if dispatch["wide_slots"]:
+        parts.append("%s (%d wide slots)" % (dispatch["wide_kernel"], dispatch["wide_slots"]))
+    if dispatch["irregular_slots"]:
+        parts.append("%s (%d irregular slots)" % (dispatch["irregular_kernels"], dispatch["irregular_slots"]))
+    if len(parts) > 1 and dispatch["irregular_slots"] > dispatch["narrow_slots"] + dispatch["wide_slots"]:
+        parts = parts[-1:] + parts[:-1]
+    return " + ".join(parts)
 
 
 def host_threads():
@@ -149,6 +156,7 @@ def main():
         elapsed = float(t.item())
     kms = dec.kernel_times_ms(min(args.steps, 64))
     kernel_ms = float(np.mean(kms)) if len(kms) else float("nan")
+    dispatch = dec.last_dispatch()
 
     # ---- bit-exactness at full size: decode(encode(pcm)) == pcm, frame counts, status -------------------
     bit_exact = None
@@ -236,7 +244,7 @@ def main():
 
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md): they cannot run
     # inside the bench, so the committed figure is used — but only if it was taken from THIS source of the kernels
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu = None, None, None
     for tdir in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r")), reverse=True):
         tpath = os.path.join(ROOT, "profiles", tdir, "traffic.json")
         if not os.path.exists(tpath):
@@ -245,9 +253,22 @@ def main():
             t = json.load(open(tpath))
             if t.get("csrc_sha256") == pkg.csrc_sha256() and t.get("workload") == [depth, ch, FL, P, args.profile]:
                 traffic, traffic_src = t["traffic_bytes_per_launch"], "profiles/%s/traffic.json" % tdir
+                valu = t.get("valu_insts_per_launch")
         except Exception:
             pass
         break
+    # The resource the kernels are actually bound by: VALU issue. A wave64 VALU instruction occupies its SIMD-32 for two
+    # cycles (MI355X_MICROARCH.md: Wave scheduling), so a launch of I wave-instructions cannot take fewer than
+    # 2 I / (CUs x 4 SIMDs) cycles; frac = that floor / the cycles of the measured launch at the device's peak clock.
+    props = torch.cuda.get_device_properties(local_rank)
+    n_simd = props.multi_processor_count * 4
+    clock_ghz = 2.4  # MI355X peak engine clock; the clock under load is lower, so frac understates the occupancy of the issue port
+    valu_issue = None
+    if valu and kernel_ms == kernel_ms:
+        cycles = kernel_ms * 1e-3 * clock_ghz * 1e9
+        valu_issue = {"insts_per_launch": int(valu), "cycles_per_inst": 2, "simds": n_simd, "clock_ghz": clock_ghz,
+                      "cycles": int(cycles), "frac": round(2.0 * valu / n_simd / cycles, 4),
+                      "source": traffic_src + " (SQ_INSTS_VALU, summed over the kernels of one decode)"}
 
     if rank == 0:
         value = samples * world * args.steps / elapsed / 1e6
@@ -266,7 +287,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None,
                          "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload and this source)") if traffic else None,
-                         "kernel": pair_kernel(depth, ch, P) if ch <= 2 else "alac_scan + alac_chan_predict + alac_interleave",
+                         "kernel": kernels_of(dispatch), "kernel_from": "alacgpu_last_dispatch: the launch plan read back from the device",
+                         "dispatch": {k: dispatch[k] for k in ("slots", "irregular_slots", "wide_slots", "narrow_slots", "keys", "packets_per_slot", "gated", "lanes_per_packet")},
+                         "valu_issue": valu_issue,
                          "kernel_ms": round(kernel_ms, 4), "kernel_ms_is": "HIP events on the handle's stream around all kernels of one decode (sort pre-pass included)",
                          "algorithmic_bytes_per_launch": alg_bytes},
             "cpu_baseline": cpu, "bit_exact": bit_exact, "gen_seconds": round(gen_s, 2), "host_entry": host_entry,

@@ -42,6 +42,10 @@ type GPUDecoder struct {
 	stride    int
 	bufOff    int // bytes of packet sampleIdx already handed out
 	packed    []byte
+
+	// a sample of the last window that could not be read (-1: none): Read fails there, behind the packets in front of it
+	lostIdx int
+	lostErr error
 }
 
 // NewGPUDecoder mirrors NewDecoder (decode.go:50-80) on the given device; window <= 0 means DefaultGPUWindow.
@@ -69,7 +73,7 @@ func NewGPUDecoder(rs io.ReadSeeker, device, window int) (*GPUDecoder, error) {
 
 	return &GPUDecoder{
 		reader: rs, dec: dec, config: config, samples: samples, window: window,
-		stride: int(config.FrameLength) * int(config.NumChannels) * bps,
+		stride: int(config.FrameLength) * int(config.NumChannels) * bps, lostIdx: -1,
 	}, nil
 }
 
@@ -132,15 +136,36 @@ func (s *GPUDecoder) fill(first int) error {
 
 	s.packed = s.packed[:total]
 
+	// A sample that cannot be read (a truncated file, a bad stco entry) must not take the intact packets in front of it
+	// with it: the reference decodes packet by packet and fails when it gets there (decode.go:157-186). The window shrinks
+	// to the packets read so far, they are decoded and served, and Read returns the error when sampleIdx reaches the lost
+	// sample (lostIdx / lostErr), as stream_decoder.hpp does with lost_ and stream.py with _w_read_err.
+	s.lostIdx, s.lostErr = -1, nil
+
 	for i := 0; i < count; i++ {
 		sample := s.samples[first+i]
-		if _, err := s.reader.Seek(int64(sample.Offset), io.SeekStart); err != nil {
-			return fmt.Errorf("seeking to sample %d at offset %d: %w", first+i, sample.Offset, err)
+
+		var err error
+		if _, err = s.reader.Seek(int64(sample.Offset), io.SeekStart); err != nil {
+			err = fmt.Errorf("seeking to sample %d at offset %d: %w", first+i, sample.Offset, err)
+		} else if _, err = io.ReadFull(s.reader, s.packed[offsets[i]:offsets[i+1]]); err != nil {
+			err = fmt.Errorf("reading sample %d: %w", first+i, err)
 		}
 
-		if _, err := io.ReadFull(s.reader, s.packed[offsets[i]:offsets[i+1]]); err != nil {
-			return fmt.Errorf("reading sample %d: %w", first+i, err)
+		if err != nil {
+			s.lostIdx, s.lostErr = first+i, err
+			count = i
+			offsets = offsets[:count+1]
+			s.packed = s.packed[:offsets[count]]
+
+			break
 		}
+	}
+
+	if count == 0 { // the window's first sample is the lost one: nothing to decode
+		s.winFirst, s.winPCM, s.winFrames, s.winStatus = first, nil, []uint32{}, nil
+
+		return nil
 	}
 
 	pcm, frames, status, err := s.dec.DecodeSamples(s.packed, offsets)
@@ -168,9 +193,17 @@ func (s *GPUDecoder) Read(p []byte) (int, error) { //nolint:varnamelen // p is i
 			return 0, io.EOF
 		}
 
+		if s.sampleIdx == s.lostIdx {
+			return total, s.lostErr
+		}
+
 		if s.winFrames == nil || s.sampleIdx < s.winFirst || s.sampleIdx >= s.winFirst+len(s.winFrames) {
 			if err := s.fill(s.sampleIdx); err != nil {
 				return total, err
+			}
+
+			if s.sampleIdx == s.lostIdx { // the window's first sample could not be read
+				return total, s.lostErr
 			}
 		}
 

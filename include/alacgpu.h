@@ -114,9 +114,10 @@ typedef struct alacgpu_decoder alacgpu_decoder;
 
 /* NewPacketDecoder (decoder.go:90). device = HIP ordinal; one stream per handle. */
 int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out);
-/* A destroyed handle's streams, events and (moderately sized) device / pinned buffers are kept for the next
- * alacgpu_create on the same device: a file decoder makes and drops a handle per file (decode.go:50-80), and building
- * one from nothing costs several times the decode of a short file. alacgpu_trim() frees what is kept. */
+/* A destroyed handle's streams, events and small buffers are kept for the next alacgpu_create on the same device: a file
+ * decoder makes and drops a handle per file (decode.go:50-80), and building one from nothing costs several times the
+ * decode of a short file. Kept per handle: at most 128 MB of device memory and 64 MB of pinned host memory (the largest
+ * buffers are dropped first); four handles per device. alacgpu_trim() frees what is kept. */
 void alacgpu_destroy(alacgpu_decoder* dec);
 void alacgpu_trim(void);
 
@@ -170,8 +171,10 @@ int alacgpu_decode_batch_device(alacgpu_decoder* dec, const uint8_t* d_blob, siz
                                 size_t n_packets, uint8_t* d_out, size_t out_stride,
                                 uint32_t* d_frames_out, int32_t* d_status, int sync);
 
-/* Device scratch the handle needs for a batch of n packets (grown on demand by the
- * batch entries; exposed so callers can pre-size before timing). */
+/* Device scratch the handle needs for a batch of n packets. The batch entries grow it on demand — and growing means
+ * hipFree + hipMalloc, which wait for the DEVICE to go idle: an alacgpu_decode_batch_device(..., sync = 0) whose batch is
+ * larger than any the handle has seen (or reserved) therefore BLOCKS until earlier work on the device is done, although
+ * it is documented as asynchronous. Callers that rely on asynchrony reserve for their largest batch first. */
 int alacgpu_reserve(alacgpu_decoder* dec, size_t n_packets);
 
 /* Duration of the last decode on this handle in milliseconds: HIP events on the handle's stream around ALL the
@@ -192,6 +195,21 @@ int alacgpu_kernel_times(alacgpu_decoder* dec, float* ms, size_t max_n, size_t* 
  * s_memtime counter (about 2.1 GHz on MI355X) when the pair began and ended the slot; [3] unused. tests/test_gpu_parity.py checks the spread over
  * the CUs, tools/pair_placement.py prints it. */
 int alacgpu_pair_placement(alacgpu_decoder* dec, uint32_t* tags, size_t max_n, size_t* n_out);
+/* Diagnostics: what the last device decode on this handle dispatched, read back from the launch plan the device built
+ * (the host only knows upper bounds when it launches): wave slots by class and the kernel that decoded the narrow
+ * regular ones — the four-wave kernel of the handle's sample width or, for 16-bit batches between the rounds, its gated
+ * twin (the device decides with the function the host repeats here on the plan's numbers). bench.py names the roofline's
+ * kernel with it. Synchronizes the handle's stream. */
+typedef struct alacgpu_dispatch {
+    uint32_t packets_per_slot;   /* 64, less for small batches */
+    uint32_t slots;              /* wave slots of the plan = irregular + wide + narrow */
+    uint32_t irregular_slots, wide_slots, narrow_slots;
+    uint32_t keys;               /* sort keys present */
+    uint32_t gated;              /* 1: the gated twin took the narrow slots */
+    uint32_t lanes_per_packet;   /* 2 / 4: predictor waves on that many lanes per packet for the long predictors; 0: none */
+    char narrow_kernel[32], wide_kernel[32], irregular_kernels[96]; /* "" when the class is empty */
+} alacgpu_dispatch;
+int alacgpu_last_dispatch(alacgpu_decoder* dec, alacgpu_dispatch* out);
 /* Placement relies on the gfx950 layout of two hardware registers read with s_getreg_b32: HW_ID (SIMD [5:4], CU [11:8],
  * shader engine [14:13]) and XCC_ID ([3:0]); the index built from them stays below 512 and a CU the census of
  * alacgpu_create() missed only loses its fixed place in the item order, so a different layout costs speed, not

@@ -39,6 +39,7 @@ pkg = importlib.import_module("saprobe-alac_amd")
 mean = lambda k, c: (sum(agg[k][c]) / len(agg[k][c])) if agg[k].get(c) else 0.0
 fetch = sum(mean(k, "FETCH_SIZE") for k in agg if "alac" in k) * 1024   # KB
 write = sum(mean(k, "WRITE_SIZE") for k in agg if "alac" in k) * 1024
+valu = sum(mean(k, "SQ_INSTS_VALU") for k in agg if "alac" in k and "census" not in k)  # wave-instructions per launch, all kernels of a decode
 import json as _j
 line = _j.load(open(os.path.join(out, "bench_under_rocprof.json")))
 wl = sys.argv[2].split()
@@ -46,7 +47,7 @@ arg = lambda k, d: int(wl[wl.index(k) + 1]) if k in wl else d
 json.dump({"workload": [arg("--depth", 16), arg("--channels", 2), arg("--frame-length", 4096), arg("--packets", 65536), arg("--profile", 0)],
            "bench_value": line.get("value"), "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"], "csrc_sha256": pkg.csrc_sha256(), "version": pkg.lib().alacgpu_version().decode(),
            "fetch_size_raw_bytes": fetch, "fetch_bytes_x2": 2 * fetch, "write_bytes": write,
-           "traffic_bytes_per_launch": int(2 * fetch + write),
+           "traffic_bytes_per_launch": int(2 * fetch + write), "valu_insts_per_launch": int(valu),
            "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, summed over the kernels of one decode; FETCH_SIZE doubled "
                   "(MI355X_MICROARCH.md: gfx950 tallies 128-B requests as 64 B)"}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(open(os.path.join(out, "traffic.json")).read())

@@ -31,10 +31,15 @@ _LIB = None
 
 __all__ = [
     "PacketConfig", "PCMFormat", "PacketDecoder", "NewPacketDecoder", "ParseMagicCookie",
-    "ErrConfig", "ErrDecode", "AlacError", "build", "lib", "lib_path",
+    "ErrConfig", "ErrDecode", "AlacError", "build", "lib", "lib_path", "trim",
 ]
 
 PACKET_PAD = 0  # ALACGPU_PACKET_PAD: blobs are dense since 0.3.0
+
+
+def trim():
+    """alacgpu_trim(): free what destroyed decoders left in the per-process handle pool (see PacketDecoder.close)."""
+    lib().alacgpu_trim()
 
 
 # ---- errors: errors.go:22-34 and internal/alac/errors.go:24-33 -------------------------------------
@@ -185,10 +190,20 @@ def csrc_sha256():
     return h.hexdigest()
 
 
+class Dispatch(ctypes.Structure):
+    """alacgpu_dispatch (include/alacgpu.h)."""
+
+    _fields_ = [("packets_per_slot", ctypes.c_uint32), ("slots", ctypes.c_uint32), ("irregular_slots", ctypes.c_uint32),
+                ("wide_slots", ctypes.c_uint32), ("narrow_slots", ctypes.c_uint32), ("keys", ctypes.c_uint32),
+                ("gated", ctypes.c_uint32), ("lanes_per_packet", ctypes.c_uint32), ("narrow_kernel", ctypes.c_char * 32),
+                ("wide_kernel", ctypes.c_char * 32), ("irregular_kernels", ctypes.c_char * 96)]
+
+
 _EXPORTS = {
     "alacgpu_create": (ctypes.c_int, [ctypes.POINTER(PacketConfig), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "alacgpu_destroy": (None, [ctypes.c_void_p]),
     "alacgpu_trim": (None, []),
+    "alacgpu_last_dispatch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "alacgpu_get_format": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PCMFormat)]),
     "alacgpu_frame_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "alacgpu_decode_packet": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
@@ -277,9 +292,17 @@ class PacketDecoder:
         self.frame_bytes = self._lib.alacgpu_frame_bytes(self._h)
 
     def close(self):
+        """alacgpu_destroy: the handle's streams, events and small buffers go to a per-process pool for the next decoder on
+        this device (at most 128 MB of device memory and 64 MB of pinned memory per pooled handle, four per device);
+        trim() gives that back too."""
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.alacgpu_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+    @staticmethod
+    def trim():
+        """alacgpu_trim: free what destroyed handles left in the pool (every device)."""
+        lib().alacgpu_trim()
 
     def __del__(self):
         try:
@@ -377,6 +400,15 @@ class PacketDecoder:
         got = ctypes.c_size_t()
         _check(self._lib.alacgpu_pair_placement(self._h, raw.ctypes.data, raw.size, ctypes.byref(got)))
         return raw[:got.value].copy()
+
+    def last_dispatch(self):
+        """What the last device decode dispatched, read back from the plan the device built (include/alacgpu.h:
+        alacgpu_last_dispatch) -> dict."""
+        d = Dispatch()
+        _check(self._lib.alacgpu_last_dispatch(self._h, ctypes.byref(d)))
+        out = {k: int(getattr(d, k)) for k, _ in Dispatch._fields_[:8]}
+        out.update({k: getattr(d, k).decode() for k in ("narrow_kernel", "wide_kernel", "irregular_kernels")})
+        return out
 
     def synchronize(self):
         _check(self._lib.alacgpu_synchronize(self._h))

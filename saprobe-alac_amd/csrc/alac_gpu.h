@@ -484,6 +484,41 @@ __global__ void alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, 
                             const alac::PktDesc* __restrict__ pd, uint8_t* __restrict__ out, uint64_t out_stride,
                             uint32_t* __restrict__ frames_out, int32_t* __restrict__ status, int32_t* __restrict__ scratch_u,
                             int32_t* __restrict__ scratch_g, uint32_t ppw);
+/* ---- which kernel takes the narrow regular wave slots of a batch (k_decode_body.inc; evaluated on the device, where the
+ * number of items is known, and again on the host for alacgpu_last_dispatch) ---- */
+constexpr __host__ __device__ __forceinline__ uint32_t pair_quota(uint32_t items, uint32_t n_cu, uint32_t cap) {
+    /* relative duration of a round with k workgroups on every CU (measured at the end of round 3, 16-bit stereo,
+     * 4096-frame packets: four-wave workgroups 1.54 2.04 2.10 2.17 ms for k = 1..4, gated pairs 2.87 3.27 ms for 5 and 6);
+     * beyond six nothing is gained (VALU issue is saturated). A heuristic: either choice decodes the same bytes. */
+    const uint32_t t[7] = {0u, 154u, 204u, 210u, 217u, 287u, 327u};
+    uint32_t best = 1u, best_cost = 0xffffffffu;
+    for (uint32_t k = 1u; k <= 6u && k <= cap; ++k) {
+        const uint32_t rounds = (items + k * n_cu - 1u) / (k * n_cu);
+        const uint32_t cost = rounds * t[k];
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = k;
+        }
+    }
+    return best;
+}
+/* more than four pairs per CU: the gated kernel's job (cap: what that kernel can hold; 0 when there is none) */
+constexpr __host__ __device__ __forceinline__ bool pair_gated(uint32_t items, uint32_t n_cu, uint32_t cap) {
+    return cap > 4u && pair_quota(items, n_cu, cap) > 4u;
+}
+/* The host launches the gated twin only for batches of more than 4 x CUs wave slots (alacgpu.hip: launch): whatever the
+ * cost table above says, it must never hand a batch that fits four rounds of the ungated kernel to the twin, or that batch
+ * stays undecoded (round 3 had such a bug once, with another guess). Checked at compile time over every item count. */
+constexpr bool pair_never_gated_within_four(uint32_t n_cu) {
+    for (uint32_t cap = 5u; cap <= 8u; ++cap)
+        for (uint32_t items = 0u; items <= 4u * n_cu; ++items)
+            if (pair_gated(items, n_cu, cap)) return false;
+    return true;
+}
+static_assert(pair_never_gated_within_four(1u) && pair_never_gated_within_four(7u) && pair_never_gated_within_four(64u) &&
+                  pair_never_gated_within_four(256u) && pair_never_gated_within_four(304u),
+              "pair_quota's table would leave batches of up to 4 x CUs wave slots to a kernel that is not launched for them");
+
 /* arguments of the pair kernels (k_decode_body.inc), passed as one struct */
 struct PairArgs {
     alac::DevCfg cfg;

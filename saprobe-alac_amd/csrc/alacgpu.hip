@@ -215,7 +215,9 @@ struct alacgpu_decoder {
     DevBuf cu_number;                                        /* PairArgs::cu_number */
     size_t chunk_bytes;                                      /* host entry: target bytes (in + out) per chunk */
     uint32_t lanes_min;                                      /* PairArgs::lanes_min; above 16: no second predictor wave for any key */
-    int side;                                                /* launch(): irregular packets on s_side (ALACGPU_SIDE: 0 never, 1 up to 6 x CUs wave slots, 2 always) */
+    int side;                                                /* launch(): irregular packets on s_side (ALACGPU_SIDE: 0 never, 1 up to 6 x CUs wave slots, 2 always: the default) */
+    size_t last_n;                                           /* the last device decode: packets, packets per wave slot, PairArgs::cap */
+    uint32_t last_ppw, last_cap;
 };
 
 namespace {
@@ -339,6 +341,9 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
     const uint32_t ppw = pick_ppw(n);
     int rc = reserve_workspace(dec, n, ppw);
     if (rc) return rc;
+    dec->last_n = n;
+    dec->last_ppw = ppw;
+    dec->last_cap = 0;
     alac::DevCfg c = dec->dev_cfg;
     c.aligned16 = (out_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(d_out) % 16) == 0) ? 1u : 0u;
     Plan* plan = (Plan*)dec->plan.p;
@@ -361,13 +366,20 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
      * (65 536 stereo packets with 328 escape packets among them: 17 + 22 + 4 us and three kernel boundaries off the
      * decode). s_side leaves `stream` behind the sort (ev_fork) and is back before the stop event (ev_join): whoever waits
      * for `stream` waits for it too. With more than two channels the scan IS the decode and everything stays in line.
-     * Only while the regular packets' workgroups (nearly) fit the device at once, up to 6 x CUs full wave slots (measured: 4 096,
-     * 32 768, 65 536, 70 000 and 98 304 packets, 16- and 24-bit: 0.8-2.2 % faster). Beyond that workgroups of later rounds
-     * wait for room, and alac_scan and alac_legacy put one workgroup per wave slot of the batch into the same wait, 26 KB of
-     * LDS and 201 registers each though nearly all of them exit at once: 131 072 packets 4.01 -> 4.49 ms, 24-bit 4.76 -> 5.90,
-     * 196 608 packets 5.78 -> 6.29 (profiles/r03_final/ab_side_stream_*.txt). Those batches keep the order of rounds 1-3. */
+     * Round 3 did this only for batches of up to 6 x CUs wave slots: alac_scan and alac_legacy were launched with one
+     * 201-register, 26-KB workgroup per wave slot of the whole batch and alac_interleave with up to 32 768 blocks, nearly all
+     * of which exit at once — but first stand in the dispatcher's line with the later rounds of the decode kernels, on a device
+     * whose register files are full (131 072 packets 4.01 -> 4.49 ms). Their grids are bounded now (scan_grid below, k_scan.hip;
+     * the interleave grid), and every batch size forks (profiles/r04_final/side_stream.txt: 131 072 packets 3.85 / 3.77 ms in
+     * line, 4.00 / 3.76 beside; 196 608: 5.62 -> 5.57; 24-bit 131 072: 4.68 -> 4.65). ALACGPU_SIDE=0: everything in line;
+     * 1: round 3's limit of 6 x CUs wave slots. */
     const bool forked = dec->cfg.num_channels <= 2 && alac::lean_config(c) &&
                         (dec->side >= 2 || (dec->side == 1 && (n + ppw - 1) / ppw <= (size_t)6 * dec->n_cu));
+    /* workgroups of alac_scan / alac_legacy: they walk the irregular wave slots (the first plan->irr_waves of the plan,
+     * a number only the device knows). Beside the regular packets' kernels: two per CU, a handful of irregular slots is the
+     * rule there; where the scan IS the decode (more than two channels, or a configuration the lean kernels do not take):
+     * as many as the device holds (201 registers: two waves per SIMD; 26 KB of LDS: six workgroups per CU). */
+    const uint32_t scan_grid = (uint32_t)std::min<size_t>(max_waves(dec, n, ppw), (size_t)(forked ? 2u : 6u) * dec->n_cu);
     hipStream_t irr = forked ? dec->s_side : dec->stream;
     if (forked) {
         HIP_TRY(hipEventRecord(dec->ev_fork, dec->stream));
@@ -376,7 +388,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
     /* from here on an error must not leave s_side running behind the caller's back */
     auto rest = [&]() -> int {
     auto scan = [&]() {
-        hipLaunchKernelGGL(alac_scan, dim3((uint32_t)max_waves(dec, n, ppw)), dim3(kWave), 0, irr, c, d_blob, blob_bytes,
+        hipLaunchKernelGGL(alac_scan, dim3(scan_grid), dim3(kWave), 0, irr, c, d_blob, blob_bytes,
                            d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, d_out, (uint64_t)out_stride, d_frames,
                            d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw, (alac::ChanDesc*)dec->cd.p,
                            (alac::PktDesc*)dec->pd.p, dec->cfg.num_channels > 2 ? (int32_t*)dec->rows.p : (int32_t*)nullptr,
@@ -398,12 +410,15 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
         /* One kernel per class of regular packets, each launched over all the wave slots; a kernel leaves the slots of the
          * other classes alone, and whether a batch is the gated twin's (16-bit, slot counts between the multiples of
          * 4 x CUs) or the four-wave kernel's is decided on the device from the plan's count of NARROW REGULAR slots
-         * (k_decode_body.inc: pair_gated): the host only knows an upper bound of all slots, so both are always launched
-         * and the one whose turn it is not exits at once. (Round 3, found by tools/gpu_fuzz.py: a host-side guess once
-         * skipped a launch the device then relied on.) */
+         * (k_decode_body.inc: pair_gated): the host only knows an upper bound of all slots. The four-wave kernel is always
+         * launched; the gated twin whenever the upper bound exceeds 4 x CUs slots — below that no count of narrow slots can
+         * make pair_gated() true (k_decode_body.inc: the static_assert on pair_never_gated_within_four), so nothing the
+         * device relies on is skipped. (Round 3, found by tools/gpu_fuzz.py: a host-side guess of another kind once did
+         * skip a launch the device then relied on.) */
         switch (dec->cfg.bit_depth) {
             case 16:
                 a.cap = pair_capacity(alac_decode_16g);
+                dec->last_cap = a.cap;
                 pairs(alac_decode_16q, 4u);
                 /* as many workgroups as the device holds at once: they share the slots out among themselves */
                 if ((size_t)slots > (size_t)4 * dec->n_cu && a.cap > 4u)
@@ -447,11 +462,13 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
         }
         /* PCM of the split packets (with one or two channels: of the escape-only packets) */
         /* a block takes eight slices of a packet at a time (k_split.hip: kSlices) */
-        const uint32_t ib = (uint32_t)std::min<uint64_t>((uint64_t)n * ((bpp + 7u) / 8u), 8192u * (256u / il_threads));
+        /* (beside the regular packets' kernels: a few blocks per CU — it walks the scanned packets, a handful there) */
+        const uint32_t ib = (uint32_t)std::min<uint64_t>((uint64_t)n * ((bpp + 7u) / 8u),
+                                                         forked ? (uint64_t)4 * dec->n_cu : (uint64_t)8192u * (256u / il_threads));
         hipLaunchKernelGGL(alac_interleave, dim3(ib), dim3(il_threads), 32u * il_threads, irr, c, d_blob, blob_bytes, d_offsets, sz,
                            (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::ChanDesc*)dec->cd.p,
                            (const alac::PktDesc*)dec->pd.p, (const int32_t*)dec->rows.p, rs, d_out, (uint64_t)out_stride, bpp);
-        hipLaunchKernelGGL(alac_legacy, dim3((uint32_t)max_waves(dec, n, ppw)), dim3(kWave), 0, irr, c, d_blob, blob_bytes,
+        hipLaunchKernelGGL(alac_legacy, dim3(scan_grid), dim3(kWave), 0, irr, c, d_blob, blob_bytes,
                            d_offsets, sz, (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::PktDesc*)dec->pd.p, d_out,
                            (uint64_t)out_stride, d_frames, d_status, (int32_t*)dec->scratch_u.p, (int32_t*)dec->scratch_g.p, ppw);
         HIP_TRY(hipGetLastError());
@@ -493,7 +510,25 @@ namespace {
 std::mutex g_pool_mu;
 std::vector<alacgpu_decoder*> g_pool;
 constexpr size_t kPoolPerDevice = 4;
-constexpr size_t kPoolBufCap = (size_t)256 << 20; /* a pooled handle keeps no single buffer larger than this */
+/* what a pooled handle keeps: device buffers of at most 128 MB in all, pinned host staging of at most 64 MB in all (the
+ * largest go first) — enough for the windows of a file decoder (stream.py: 4 096 packets), not the workspace of a
+ * 65 536-packet batch. Four handles per device: at most 0.5 GB of device memory and 0.25 GB of pinned memory per device
+ * stay allocated behind alacgpu_destroy() until alacgpu_trim(). */
+constexpr size_t kPoolKeepDevice = (size_t)128 << 20;
+constexpr size_t kPoolKeepPinned = (size_t)64 << 20;
+template <class Buf>
+void keep_at_most(std::vector<Buf*> bufs, size_t limit) {
+    for (;;) {
+        size_t total = 0;
+        Buf* big = nullptr;
+        for (Buf* b : bufs) {
+            total += b->cap;
+            if (b->cap && (!big || b->cap > big->cap)) big = b;
+        }
+        if (total <= limit || !big) return;
+        big->release();
+    }
+}
 
 void really_destroy(alacgpu_decoder* d) {
     (void)hipSetDevice(d->device);
@@ -535,14 +570,16 @@ void configure(alacgpu_decoder* d, const alacgpu_config* cfg, int bps) {
     d->dev_cfg = alac::DevCfg{cfg->frame_length, cfg->bit_depth, cfg->num_channels, cfg->pb, cfg->mb, cfg->kb,
                               (uint32_t)bps, 0u};
     d->launches = 0;
+    d->last_n = 0;
+    d->last_ppw = d->last_cap = 0;
     d->il_threads = 64;
     if (const char* e = getenv("ALACGPU_IL_THREADS")) {
         const int v = atoi(e);
         if (v == 64 || v == 128 || v == 256) d->il_threads = (uint32_t)v;
     }
-    d->lanes_min = 9;
+    d->lanes_min = 4;
     if (const char* e = getenv("ALACGPU_LANES_MIN")) d->lanes_min = (uint32_t)std::max(1, atoi(e)); /* experiments; 17: never */
-    d->side = 1;
+    d->side = 2;
     if (const char* e = getenv("ALACGPU_SIDE")) d->side = atoi(e); /* experiments, tests */
     d->chunk_bytes = (size_t)192 << 20;
     if (const char* e = getenv("ALACGPU_CHUNK_MB")) {
@@ -604,18 +641,9 @@ int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out)
     hipError_t e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_in, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_out, hipStreamNonBlocking);
+    /* (the default priority: at the lowest one the side kernels linger until the decode's last workgroups have gone and
+     * become its tail: 131 072 packets 3.85 -> 4.38 ms, 24-bit 4.68 -> 5.97; profiles/r04_final/side_stream.txt) */
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_side, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming);
-    for (uint32_t i = 0; i < kTimingSlots && e == hipSuccess; i++) {
-        e = hipEventCreate(&d->ev_start[i]);
-        if (e == hipSuccess) e = hipEventCreate(&d->ev_stop[i]);
-    }
-    for (int k = 0; k < kSlots && e == hipSuccess; k++) {
-        e = hipEventCreateWithFlags(&d->slots[k].ev_in, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->slots[k].ev_k, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->slots[k].ev_out, hipEventDisableTiming);
-    }
     if (e != hipSuccess) {
         set_err("stream/event creation failed: %s", hipGetErrorString(e));
         really_destroy(d);
@@ -637,17 +665,18 @@ void alacgpu_destroy(alacgpu_decoder* d) {
               hipStreamSynchronize(d->s_out) == hipSuccess && hipStreamSynchronize(d->s_side) == hipSuccess;
     if (ok) {
         for (int k = 0; k < kSlots; k++) d->slots[k].busy = false;
-        DevBuf* bufs[] = {&d->scratch_u, &d->scratch_g, &d->plan, &d->cls, &d->perm, &d->sizes_ws, &d->cd, &d->pd,
-                          &d->plan2, &d->keys2, &d->perm2, &d->rows};
-        for (DevBuf* b : bufs)
-            if (b->cap > kPoolBufCap) b->release();
+        std::vector<DevBuf*> dev = {&d->scratch_u, &d->scratch_g, &d->plan, &d->cls, &d->perm, &d->sizes_ws, &d->cd, &d->pd,
+                                    &d->plan2, &d->keys2, &d->perm2, &d->rows};
+        std::vector<decltype(&d->slots[0].h_in)> pinned;
         for (int k = 0; k < kSlots; k++) {
             Slot& s = d->slots[k];
-            if (s.d_in.cap > kPoolBufCap) s.d_in.release();
-            if (s.d_out.cap > kPoolBufCap) s.d_out.release();
-            if (s.h_in.cap > kPoolBufCap) s.h_in.release();
-            if (s.h_out.cap > kPoolBufCap) s.h_out.release();
+            dev.push_back(&s.d_in);
+            dev.push_back(&s.d_out);
+            pinned.push_back(&s.h_in);
+            pinned.push_back(&s.h_out);
         }
+        keep_at_most(dev, kPoolKeepDevice);
+        keep_at_most(pinned, kPoolKeepPinned);
         std::lock_guard<std::mutex> g(g_pool_mu);
         size_t same = 0;
         for (alacgpu_decoder* p : g_pool) same += p->device == d->device ? 1u : 0u;
@@ -948,6 +977,40 @@ int alacgpu_pair_placement(alacgpu_decoder* d, uint32_t* tags, size_t max_n, siz
     if (plan_bytes(n) > d->plan.cap) return ALACGPU_E_ARG;
     if (n) HIP_TRY(hipMemcpy(tags, (const uint8_t*)d->plan.p + plan_claims_offset(), n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     *n_out = n;
+    return ALACGPU_E_OK;
+}
+
+int alacgpu_last_dispatch(alacgpu_decoder* d, alacgpu_dispatch* out) {
+    if (!d || !out) return ALACGPU_E_ARG;
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    memset(out, 0, sizeof(*out));
+    if (!d->plan.p || d->last_n == 0) return ALACGPU_E_OK;
+    Plan head;
+    HIP_TRY(hipMemcpy(&head, d->plan.p, sizeof(Plan), hipMemcpyDeviceToHost));
+    out->packets_per_slot = d->last_ppw;
+    out->slots = head.total_waves;
+    out->irregular_slots = head.irr_waves;
+    out->wide_slots = head.wide_waves;
+    out->narrow_slots = head.total_waves - head.irr_waves - head.wide_waves;
+    out->keys = head.nk;
+    const bool lean = d->cfg.num_channels <= 2 && alac::lean_config(d->dev_cfg);
+    /* the device's own decision (k_decode_body.inc reads the same plan and calls the same function) */
+    const char* narrow = "";
+    if (lean && out->narrow_slots) {
+        const char* q = d->cfg.bit_depth == 16 ? "alac_decode_16q" : d->cfg.bit_depth == 32 ? "alac_decode_32q" : "alac_decode_24q";
+        narrow = (d->cfg.bit_depth == 16 && pair_gated(out->narrow_slots, d->n_cu, d->last_cap)) ? "alac_decode_16g" : q;
+        out->gated = narrow[14] == 'g' ? 1u : 0u;
+        /* predictor waves on several lanes per packet (k_decode_body.inc: lanes_ok) */
+        if (!out->gated && out->narrow_slots <= d->n_cu + d->n_cu / 8u && d->lanes_min <= 16u) out->lanes_per_packet = d->last_ppw <= 32u ? 4u : 2u;
+    }
+    snprintf(out->narrow_kernel, sizeof(out->narrow_kernel), "%s", narrow);
+    snprintf(out->wide_kernel, sizeof(out->wide_kernel), "%s",
+             (lean && out->wide_slots) ? (d->cfg.bit_depth == 32 ? "alac_decode_w32" : "alac_decode_w24") : "");
+    snprintf(out->irregular_kernels, sizeof(out->irregular_kernels), "%s",
+             !out->irregular_slots ? "" : !alac::lean_config(d->dev_cfg) ? "alac_scan (whole-packet decoder)"
+             : d->cfg.num_channels > 2 ? "alac_scan + alac_chan_predict + alac_interleave (+ alac_legacy)"
+                                       : "alac_scan + alac_interleave (+ alac_legacy)");
     return ALACGPU_E_OK;
 }
 

@@ -7,7 +7,20 @@ namespace alack {
 
 /* Irregular packets (keys >= KEY_IRREGULAR; they own the first plan->irr_waves wave slots): one wavefront per 64 packets.
  * With a usable KB they are scanned (status, frame count, channel descriptors: split pipeline step 1, PCM comes
- * from the later kernels); with KB == 0 the whole-packet decoder takes them. */
+ * from the later kernels); with KB == 0 the whole-packet decoder takes them.
+ * A BOUNDED grid (round 4): the host does not know how many of a batch's wave slots are irregular, and until round 3 it
+ * launched one 201-register, 26-KB workgroup per wave slot of the whole batch, nearly all of which left at once — but
+ * first stood in the dispatcher's line with the later rounds of the decode kernels (which is what kept these kernels off
+ * the side stream for large batches). Now the grid is a few workgroups per CU (alacgpu.hip: scan_grid) and workgroup g
+ * walks slots g, g + gridDim.x, ... below plan->irr_waves: an exit condition every wave reaches. */
+static __device__ __forceinline__ void scan_slot(uint32_t b, const alac::DevCfg& cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes,
+                                                 const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ sizes,
+                                                 const uint32_t* __restrict__ perm, const Plan* __restrict__ plan, uint8_t* __restrict__ out,
+                                                 uint64_t out_stride, uint32_t* __restrict__ frames_out, int32_t* __restrict__ status,
+                                                 int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g, uint32_t ppw,
+                                                 alac::ChanDesc* __restrict__ cd, alac::PktDesc* __restrict__ pd, int32_t* __restrict__ rows,
+                                                 uint64_t row_stride);
+
 __global__ void __launch_bounds__(kWave)
 alac_scan(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
           const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
@@ -15,8 +28,21 @@ alac_scan(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_byte
           int32_t* __restrict__ status, int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g,
           uint32_t ppw, alac::ChanDesc* __restrict__ cd, alac::PktDesc* __restrict__ pd, int32_t* __restrict__ rows,
           uint64_t row_stride) {
-    const uint32_t b = blockIdx.x;
-    if (b >= plan->irr_waves) return;
+    const uint32_t limit = plan->irr_waves;
+    for (uint32_t b = blockIdx.x; b < limit; b += gridDim.x) {
+        scan_slot(b, cfg, blob, blob_bytes, offsets, sizes, perm, plan, out, out_stride, frames_out, status, scratch_u, scratch_g, ppw,
+                  cd, pd, rows, row_stride);
+        __builtin_amdgcn_wave_barrier(); /* (one wave per workgroup: the LDS rows are the next slot's from here on) */
+    }
+}
+
+static __device__ __forceinline__ void scan_slot(uint32_t b, const alac::DevCfg& cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes,
+                                                 const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ sizes,
+                                                 const uint32_t* __restrict__ perm, const Plan* __restrict__ plan, uint8_t* __restrict__ out,
+                                                 uint64_t out_stride, uint32_t* __restrict__ frames_out, int32_t* __restrict__ status,
+                                                 int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g, uint32_t ppw,
+                                                 alac::ChanDesc* __restrict__ cd, alac::PktDesc* __restrict__ pd, int32_t* __restrict__ rows,
+                                                 uint64_t row_stride) {
     uint32_t e = 0;
     for (uint32_t t = 1; t < plan->nk; ++t)
         if (plan->list_wave0[t] <= b) e = t;
@@ -55,15 +81,33 @@ alac_scan(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_byte
     }
 }
 
-/* packets the scan routed to the whole-packet decoder (orders 17..30): same wave mapping as the ungated pair kernels */
+/* packets the scan routed to the whole-packet decoder (orders 17..30): the scanned slots again, the same bounded grid */
+static __device__ __forceinline__ void legacy_slot(uint32_t b, const alac::DevCfg& cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes,
+                                                   const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ sizes,
+                                                   const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+                                                   const alac::PktDesc* __restrict__ pd, uint8_t* __restrict__ out, uint64_t out_stride,
+                                                   uint32_t* __restrict__ frames_out, int32_t* __restrict__ status,
+                                                   int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g, uint32_t ppw);
+
 __global__ void __launch_bounds__(kWave)
 alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
             const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
             const alac::PktDesc* __restrict__ pd, uint8_t* __restrict__ out, uint64_t out_stride,
             uint32_t* __restrict__ frames_out, int32_t* __restrict__ status, int32_t* __restrict__ scratch_u,
             int32_t* __restrict__ scratch_g, uint32_t ppw) {
-    const uint32_t b = blockIdx.x;
-    if (b >= plan->total_waves) return;
+    const uint32_t limit = plan->irr_waves; /* kKeyScan slots are irregular ones: the first of the plan */
+    for (uint32_t b = blockIdx.x; b < limit; b += gridDim.x) {
+        legacy_slot(b, cfg, blob, blob_bytes, offsets, sizes, perm, plan, pd, out, out_stride, frames_out, status, scratch_u, scratch_g, ppw);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+static __device__ __forceinline__ void legacy_slot(uint32_t b, const alac::DevCfg& cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes,
+                                                   const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ sizes,
+                                                   const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+                                                   const alac::PktDesc* __restrict__ pd, uint8_t* __restrict__ out, uint64_t out_stride,
+                                                   uint32_t* __restrict__ frames_out, int32_t* __restrict__ status,
+                                                   int32_t* __restrict__ scratch_u, int32_t* __restrict__ scratch_g, uint32_t ppw) {
     uint32_t e = 0;
     for (uint32_t t = 1; t < plan->nk; ++t)
         if (plan->list_wave0[t] <= b) e = t;

@@ -62,6 +62,12 @@ public:
             if (e) std::rethrow_exception(e);
     }
 
+    // the decoders' shard-sized workspaces are nothing a later small decoder would want to inherit from the pool
+    ~ShardedDecoder() {
+        decoders_.clear();
+        PacketDecoder::Trim();
+    }
+
 private:
     std::vector<std::unique_ptr<PacketDecoder>> decoders_;
 };

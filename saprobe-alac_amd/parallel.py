@@ -47,9 +47,15 @@ class ShardedDecoder:
         self.devices = list(devices)
         self.decoders = [make_decoder(config, d) for d in self.devices]
 
-    def close(self):
+    def close(self, trim=True):
+        """Destroys the per-device decoders; trim: also empty the library's handle pool (a sharded batch decoder's
+        workspaces are the size of its shards: nothing a later small decoder would want to inherit)."""
         for d in self.decoders:
             d.close()
+        if trim and self.decoders:
+            trim_fn = getattr(type(self.decoders[0]), "trim", None)
+            if trim_fn is not None:
+                trim_fn()
 
     def decode_batch(self, blob, offsets):
         """Host blob + offsets[n+1] -> (out[n, stride], frames, status), slices decoded concurrently."""

@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     if (strstr(alacgpu_version(), "gfx950") == NULL) return 1;
     if (link_only) {
         /* take the address of every entry point so that the linker must resolve it */
-        void (*fns[16])(void);
+        void (*fns[24])(void);
         size_t i = 0;
         fns[i++] = (void (*)(void))alacgpu_create;
         fns[i++] = (void (*)(void))alacgpu_destroy;
@@ -74,6 +74,9 @@ int main(int argc, char** argv) {
         fns[i++] = (void (*)(void))alacgpu_synchronize;
         fns[i++] = (void (*)(void))alacgpu_last_error;
         fns[i++] = (void (*)(void))alacgpu_version;
+        fns[i++] = (void (*)(void))alacgpu_trim;
+        fns[i++] = (void (*)(void))alacgpu_pair_placement;
+        fns[i++] = (void (*)(void))alacgpu_last_dispatch;
         while (i--)
             if (fns[i] == NULL) return 1;
         printf("c_abi smoke: linked, %s\n", alacgpu_version());

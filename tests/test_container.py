@@ -297,6 +297,24 @@ def test_cpp_streaming_decoder(pkg, synth, oracle):
             assert L.shim_read(h, out, ctypes.c_size_t(10)) == -3
             assert bytes(got) == b"".join(want[:77])
         L.shim_close(h)
+    # TestDecode_TruncatedPacket (tests/error_test.go:413-442): the file ends inside the last packets. Everything in front of
+    # the first sample that cannot be read is delivered (it sits in the middle of a read-ahead window), then the read error,
+    # on every further Read (decode.go:157-186; the Go twin go/alacgpu_decoder.go: lostIdx does the same)
+    data = m4a.write_m4a(cfg, packets)
+    cut = data[:len(data) - len(packets[-1]) - len(packets[-2]) - 5]
+    buf = (ctypes.c_uint8 * len(cut)).from_buffer_copy(cut)
+    h = ctypes.c_void_p()
+    assert L.shim_open(buf, ctypes.c_size_t(len(cut)), ctypes.c_size_t(32), ctypes.byref(h)) == 0, L.shim_last_error()
+    got = bytearray()
+    while True:
+        n = L.shim_read(h, out, ctypes.c_size_t(100003))
+        if n <= 0:
+            break
+        got += bytes(out[:n])
+    assert n == -4 and b"reading sample 117" in L.shim_last_error()                     # ErrRead
+    assert bytes(got) == b"".join(want[:117])
+    assert L.shim_read(h, out, ctypes.c_size_t(10)) == -4
+    L.shim_close(h)
     h = ctypes.c_void_p()
     junk = (ctypes.c_uint8 * 64)()
     assert L.shim_open(junk, ctypes.c_size_t(64), ctypes.c_size_t(8), ctypes.byref(h)) == -1     # ErrNoTrack

@@ -5,6 +5,9 @@ device-resident batch; prints the per-build median of the HIP-event decode time.
 
     python tools/ab_bench.py [--packets 65536 --depth 16 --channels 2 --profile 0] libA.so libB.so ...
 
+A build may be given as path@NAME=value[,NAME=value]: those environment variables are set while its handle is made (the
+library reads ALACGPU_SIDE, ALACGPU_LANES_MIN, ... per handle), so one binary can be compared with itself under two settings.
+
 Builds with the round-1 ABI (alacgpu 0.2.x: no blob_bytes argument, 64 zero bytes behind every packet) are driven
 through their own signature; the batch is laid out with padding so both kinds can read it."""
 import argparse
@@ -51,7 +54,13 @@ def main():
     torch.cuda.synchronize()
     vp, sz = ctypes.c_void_p, ctypes.c_size_t
     builds = []
-    for path in args.libs:
+    for spec in args.libs:
+        path, _, envs = spec.partition("@")
+        saved = {}
+        for kv in filter(None, envs.split(",")):
+            k, _, v = kv.partition("=")
+            saved[k] = os.environ.get(k)
+            os.environ[k] = v
         L = ctypes.CDLL(os.path.abspath(path))
         L.alacgpu_version.restype = ctypes.c_char_p
         ver = L.alacgpu_version().decode()
@@ -66,7 +75,12 @@ def main():
         h = vp()
         assert L.alacgpu_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == 0
         L.alacgpu_reserve(h, P)
-        builds.append({"path": path, "version": ver, "L": L, "h": h, "old": old, "ms": []})
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        builds.append({"path": spec, "version": ver, "L": L, "h": h, "old": old, "ms": []})
 
     def run(bd, steps):
         L, h = bd["L"], bd["h"]
