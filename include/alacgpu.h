@@ -121,6 +121,13 @@ int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out)
 void alacgpu_destroy(alacgpu_decoder* dec);
 void alacgpu_trim(void);
 
+/* Pinned (page-locked) host memory for the buffers a caller hands to alacgpu_decode_batch: what that entry finds in pinned
+ * memory it transfers in place instead of through its own staging copies (a third of the time of a file decode goes into
+ * those). NULL when the runtime refuses. Freed buffers of up to 64 MB are kept for the next alacgpu_host_alloc (at most
+ * four; alacgpu_trim() frees them). */
+void* alacgpu_host_alloc(size_t bytes);
+void alacgpu_host_free(void* p);
+
 /* (*PacketDecoder).Format (decoder.go:112). */
 int alacgpu_get_format(const alacgpu_decoder* dec, alacgpu_format* fmt);
 

@@ -203,6 +203,8 @@ _EXPORTS = {
     "alacgpu_create": (ctypes.c_int, [ctypes.POINTER(PacketConfig), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "alacgpu_destroy": (None, [ctypes.c_void_p]),
     "alacgpu_trim": (None, []),
+    "alacgpu_host_alloc": (ctypes.c_void_p, [ctypes.c_size_t]),
+    "alacgpu_host_free": (None, [ctypes.c_void_p]),
     "alacgpu_last_dispatch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "alacgpu_get_format": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(PCMFormat)]),
     "alacgpu_frame_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
@@ -358,7 +360,9 @@ class PacketDecoder:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
         stride = out_stride or self.frame_bytes
-        out = np.zeros((max(n, 0), stride), dtype=np.uint8)
+        # (empty, not zeros: the entry itself zeroes failing packets' slots and the bytes behind partial frames, and touching
+        # 50 MB twice is a third of a long file's decode time)
+        out = np.empty((max(n, 0), stride), dtype=np.uint8)
         frames = np.zeros(max(n, 0), dtype=np.uint32)
         status = np.zeros(max(n, 0), dtype=np.int32)
         if n > 0:

@@ -222,7 +222,11 @@ constexpr uint32_t kFlush = kRing / 2;                      /* dwords per lane a
 constexpr uint32_t kRowStride = kRing + 1;                  /* odd stride = conflict-free column access */
 constexpr uint32_t kFallbackSlots = 64;
 constexpr uint32_t kRingDw = ALAC_LDS_RING;                 /* bitstream ring, dwords per lane */
-constexpr uint32_t kRingStride = kRingDw + 4;               /* rows stay 16-byte aligned, lanes spread over banks */
+/* Bitstream rings, SLOT-major (round 4): slot s of all 64 lanes lies side by side (s_ring[s * 64 + lane]), so that a
+ * wave's access to ANY mix of slots — the lanes' positions drift apart — is free of bank conflicts (the bank is the lane's).
+ * Rounds 1-3 had a row of 36 dwords per lane: lanes l and l + 8 shared a bank, and since round 4 the step's window read
+ * sits in the entropy chain (alac_regular.h: RingRd). Two spare slots behind the ring: slot kRingDw repeats slot 0. */
+constexpr uint32_t kRingSlots = kRingDw + 2;
 
 /* device-side launch plan, rebuilt by every decode */
 /* sort keys: 0..2047 regular packets (numU*32 + numV + KEY_WIDE, alac_regular.h); 2048 / 2049 irregular packets
@@ -255,7 +259,7 @@ struct Plan {
  * every access is a ds_* instruction (a pointer kept in a struct decays to flat_* loads and stores). */
 static __shared__ uint32_t s_rows[kWave * kRowStride];                                  /* PCM stager rows */
 static __shared__ unsigned long long s_optr[kWave];                                     /* PCM slot of each lane's packet */
-static __shared__ __attribute__((aligned(16))) uint32_t s_ring[kWave * kRingStride];    /* bitstream rings */
+static __shared__ __attribute__((aligned(16))) uint32_t s_ring[kRingSlots * kWave];     /* bitstream rings */
 /* residual queue of the wave pair (alac_duo.h), A -> B, double-buffered chunks */
 constexpr uint32_t kQ = alac::DUO_CHUNK;
 /* rows per buffer: a chunk of residuals A -> B; where another wave writes the PCM (alac_duo.h: EMIT_A) half a chunk of
@@ -378,25 +382,28 @@ struct GpuWave {
         flushed = wcnt;
         return wcnt;
     }
-    /* bitstream ring of the entropy wave: kRingDw dwords per lane, rows of kRingStride dwords (16-byte aligned) */
+    /* bitstream ring of the entropy wave: kRingDw dwords per lane, slot-major (kRingSlots) */
     ALAC_DEV void ring_write4(uint32_t slot, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-        /* (slot >> 2) * 4 lets the compiler see the 16-byte alignment: one ds_write_b128 */
-        *reinterpret_cast<uint4*>(&s_ring[lane * kRingStride + (slot >> 2) * 4u]) = make_uint4(a, b, c, d);
+        uint32_t* q = &s_ring[slot * kWave + lane]; /* two ds_write2st64_b32 */
+        q[0] = a;
+        q[kWave] = b;
+        q[2 * kWave] = c;
+        q[3 * kWave] = d;
     }
-    ALAC_DEV uint32_t ring_read(uint32_t slot) const { return s_ring[lane * kRingStride + slot]; }
-    /* slots `slot` and `slot + 1` in one ds_read2_b32 (slot <= kRingDw - 1: slot kRingDw repeats slot 0, RingRd::commit) */
+    ALAC_DEV uint32_t ring_read(uint32_t slot) const { return s_ring[slot * kWave + lane]; }
+    /* slots `slot` and `slot + 1` in one ds_read2st64_b32 (slot <= kRingDw - 1: slot kRingDw repeats slot 0, RingRd::commit) */
     ALAC_DEV void ring_read2(uint32_t slot, uint32_t& a, uint32_t& b) const {
-        const uint32_t* q = &s_ring[lane * kRingStride + slot];
+        const uint32_t* q = &s_ring[slot * kWave + lane];
         a = q[0];
-        b = q[1];
+        b = q[kWave];
     }
-    /* the same by the slot's byte offset in the lane's row (4 * slot) */
+    /* the same by 4 * slot (what gol_step has at hand: one v_lshl_add_u32 to the address) */
     ALAC_DEV void ring_read2_at(uint32_t byte_off, uint32_t& a, uint32_t& b) const {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(&s_ring[lane * kRingStride]) + byte_off);
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(&s_ring[lane]) + byte_off * kWave);
         a = q[0];
-        b = q[1];
+        b = q[kWave];
     }
-    ALAC_DEV void ring_write1(uint32_t slot, uint32_t v) { s_ring[lane * kRingStride + slot] = v; }
+    ALAC_DEV void ring_write1(uint32_t slot, uint32_t v) { s_ring[slot * kWave + lane] = v; }
     /* residual queue: row j of buffer buf holds step j of the chunk for all 64 lanes (conflict-free) */
     ALAC_DEV void rq_write(uint32_t buf, uint32_t j, int32_t v) { s_rq[(buf * kQRows + j) * kWave + lane] = v; }
     ALAC_DEV int32_t rq_read(uint32_t buf, uint32_t j) const { return s_rq[(buf * kQRows + j) * kWave + lane]; }

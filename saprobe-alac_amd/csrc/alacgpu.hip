@@ -509,6 +509,8 @@ bool is_pinned(const void* p) {
 namespace {
 std::mutex g_pool_mu;
 std::vector<alacgpu_decoder*> g_pool;
+std::vector<std::pair<void*, size_t>> g_host_pool;  /* alacgpu_host_free: pinned buffers waiting for the next alacgpu_host_alloc */
+std::vector<std::pair<void*, size_t>> g_host_sizes; /* live alacgpu_host_alloc buffers and their sizes */
 constexpr size_t kPoolPerDevice = 4;
 /* what a pooled handle keeps: device buffers of at most 128 MB in all, pinned host staging of at most 64 MB in all (the
  * largest go first) — enough for the windows of a file decoder (stream.py: 4 096 packets), not the workspace of a
@@ -644,6 +646,17 @@ int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out)
     /* (the default priority: at the lowest one the side kernels linger until the decode's last workgroups have gone and
      * become its tail: 131 072 packets 3.85 -> 4.38 ms, 24-bit 4.68 -> 5.97; profiles/r04_final/side_stream.txt) */
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->s_side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming);
+    for (uint32_t i = 0; i < kTimingSlots && e == hipSuccess; i++) {
+        e = hipEventCreate(&d->ev_start[i]);
+        if (e == hipSuccess) e = hipEventCreate(&d->ev_stop[i]);
+    }
+    for (int k = 0; k < kSlots && e == hipSuccess; k++) {
+        e = hipEventCreateWithFlags(&d->slots[k].ev_in, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->slots[k].ev_k, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->slots[k].ev_out, hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         set_err("stream/event creation failed: %s", hipGetErrorString(e));
         really_destroy(d);
@@ -690,11 +703,64 @@ void alacgpu_destroy(alacgpu_decoder* d) {
 
 void alacgpu_trim(void) {
     std::vector<alacgpu_decoder*> all;
+    std::vector<std::pair<void*, size_t>> host;
     {
         std::lock_guard<std::mutex> g(g_pool_mu);
         all.swap(g_pool);
+        host.swap(g_host_pool);
     }
     for (alacgpu_decoder* d : all) really_destroy(d);
+    for (auto& h : host) (void)hipHostFree(h.first);
+}
+
+/* Pinned host memory for a caller's PCM (or packet) buffers: what alacgpu_decode_batch finds in pinned memory it
+ * transfers in place, without the copy through its staging. Freed buffers of up to 64 MB are kept (at most four, the
+ * smallest that fits is handed out again): a file decoder asks for the same sizes file after file, and hipHostMalloc
+ * costs milliseconds. */
+void* alacgpu_host_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < g_host_pool.size(); i++)
+            if (g_host_pool[i].second >= bytes && g_host_pool[i].second <= 2 * bytes + (1u << 20) &&
+                (best == SIZE_MAX || g_host_pool[i].second < g_host_pool[best].second))
+                best = i;
+        if (best != SIZE_MAX) {
+            void* p = g_host_pool[best].first;
+            g_host_sizes.emplace_back(p, g_host_pool[best].second);
+            g_host_pool.erase(g_host_pool.begin() + (long)best);
+            return p;
+        }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        set_err("hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    g_host_sizes.emplace_back(p, bytes);
+    return p;
+}
+
+void alacgpu_host_free(void* p) {
+    if (!p) return;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        for (size_t i = 0; i < g_host_sizes.size(); i++)
+            if (g_host_sizes[i].first == p) {
+                bytes = g_host_sizes[i].second;
+                g_host_sizes.erase(g_host_sizes.begin() + (long)i);
+                break;
+            }
+        if (bytes && bytes <= ((size_t)64 << 20) && g_host_pool.size() < 4) {
+            g_host_pool.emplace_back(p, bytes);
+            return;
+        }
+    }
+    (void)hipHostFree(p);
 }
 
 int alacgpu_get_format(const alacgpu_decoder* d, alacgpu_format* fmt) {

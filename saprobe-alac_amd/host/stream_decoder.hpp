@@ -4,11 +4,15 @@
 // Same surface (NewDecoder, Format, Duration, Position, Seek, Read) and the same observable behaviour: PCM bytes
 // in packet order, packet-aligned seeks, the error of packet k when the reader reaches packet k and again on every
 // later Read. The PCM is made differently: a window of packets goes through ONE batch decode on the GPU
-// (alacgpu_decode_batch) and Read / Seek are served from the decoded window. Header-only; link with -lalacgpu.
+// (alacgpu_decode_batch) and Read / Seek are served from the decoded window — and while the caller drains window k, a
+// worker thread has window k + 1 decoded into a second buffer (round 4: a 300-second file spent as long in Read's copies
+// as in the decode; now the two overlap). Window PCM lives in pinned memory (alacgpu_host_alloc): the device writes it
+// there directly. Header-only; link with -lalacgpu -pthread.
 #pragma once
 
 #include <algorithm>
 #include <cstring>
+#include <future>
 
 #include "mp4_demux.hpp"
 #include "packet_decoder.hpp"
@@ -46,8 +50,9 @@ inline PacketConfig ParseMagicCookie(const uint8_t* d, size_t n) {
 
 class Decoder {
 public:
-    // The file must stay mapped / alive for the lifetime of the decoder. window = packets per batch decode.
-    Decoder(const uint8_t* file, size_t len, int device = 0, size_t window = 4096) : file_(file), len_(len), window_(std::max<size_t>(1, window)) {
+    // The file must stay mapped / alive for the lifetime of the decoder. window = packets per batch decode (the read-ahead
+    // runs one window ahead of the reader; 1024 packets are 16 MB of CD audio).
+    Decoder(const uint8_t* file, size_t len, int device = 0, size_t window = 1024) : file_(file), len_(len), window_(std::max<size_t>(1, window)) {
         try {
             track_ = mp4::FindALACTrack(file, len);
         } catch (const mp4::Error& e) {
@@ -63,6 +68,12 @@ public:
         const unsigned bps = config_.bit_depth == 16 ? 2 : config_.bit_depth == 32 ? 4 : 3;
         bpf_ = (size_t)config_.num_channels * bps;
     }
+    ~Decoder() {
+        Settle();
+        for (Window& w : win_) w.Free();
+    }
+    Decoder(const Decoder&) = delete;
+    Decoder& operator=(const Decoder&) = delete;
 
     PCMFormat Format() const { return dec_->Format(); }
     const PacketConfig& Config() const { return config_; }
@@ -109,50 +120,106 @@ public:
     }
 
 private:
-    void DecodeWindow(size_t first) {
+    // one decoded window: packets [w0, w1); `lost`: the first sample behind it that lies outside the file (decode.go:163-169)
+    struct Window {
+        size_t w0 = 0, w1 = 0, lost = SIZE_MAX;
+        uint8_t* out = nullptr;  // pinned when the runtime grants it
+        size_t cap = 0;
+        bool pinned = false;
+        std::vector<uint64_t> starts;
+        std::vector<uint8_t> gather;
+        std::vector<uint32_t> frames;
+        std::vector<int32_t> status;
+        bool Holds(size_t k) const { return (w0 <= k && k < w1) || lost == k; }
+        void Reserve(size_t bytes) {
+            if (bytes <= cap) return;
+            Free();
+            out = static_cast<uint8_t*>(alacgpu_host_alloc(bytes));
+            pinned = out != nullptr;
+            if (!out) out = static_cast<uint8_t*>(::operator new(bytes));  // pageable: the library stages the copy
+            cap = bytes;
+        }
+        void Free() {
+            if (out && pinned) alacgpu_host_free(out);
+            else if (out) ::operator delete(out);
+            out = nullptr;
+            cap = 0;
+        }
+    };
+
+    // packets [first, first + window) into w: one batch decode (runs on the caller's thread or on the read-ahead worker:
+    // never both at once, the handle is not safe for concurrent use)
+    void DecodeWindow(Window& w, size_t first) {
         size_t last = std::min(first + window_, Packets());
-        lost_ = SIZE_MAX;
+        w.lost = SIZE_MAX;
         for (size_t k = first; k < last; ++k)
             if (track_.offsets[k] > len_ || track_.sizes[k] > len_ - track_.offsets[k]) {
-                lost_ = k;
+                w.lost = k;
                 last = k;
                 break;
             }
         const size_t n = last - first;
-        starts_.assign(n + 1, 0);
-        for (size_t k = 0; k < n; ++k) starts_[k + 1] = starts_[k] + track_.sizes[first + k];
+        w.starts.assign(n + 1, 0);
+        for (size_t k = 0; k < n; ++k) w.starts[k + 1] = w.starts[k] + track_.sizes[first + k];
         bool run = true;
         for (size_t k = 1; k < n && run; ++k) run = track_.offsets[first + k] == track_.offsets[first + k - 1] + track_.sizes[first + k - 1];
         const uint8_t* blob = n ? file_ + track_.offsets[first] : nullptr;  // one mdat run: no gather
         size_t blob_bytes = n ? (size_t)(len_ - track_.offsets[first]) : 0;
         if (!run) {
-            gather_.resize(starts_[n] + 1);
-            for (size_t k = 0; k < n; ++k) memcpy(gather_.data() + starts_[k], file_ + track_.offsets[first + k], track_.sizes[first + k]);
-            blob = gather_.data();
-            blob_bytes = (size_t)starts_[n];
+            w.gather.resize(w.starts[n] + 1);
+            for (size_t k = 0; k < n; ++k) memcpy(w.gather.data() + w.starts[k], file_ + track_.offsets[first + k], track_.sizes[first + k]);
+            blob = w.gather.data();
+            blob_bytes = (size_t)w.starts[n];
         }
         if (n) {
             static const uint8_t none = 0;
-            if (starts_[n] == 0) {
+            if (w.starts[n] == 0) {
                 blob = &none;
                 blob_bytes = 0;
             }
-            out_.resize(n * stride_);
-            frames_.resize(n);
-            status_.resize(n);
-            dec_->DecodePackets(blob, blob_bytes, starts_.data(), n, out_.data(), stride_, frames_.data(), status_.data());
+            w.Reserve(n * stride_);
+            w.frames.resize(n);
+            w.status.resize(n);
+            dec_->DecodePackets(blob, blob_bytes, w.starts.data(), n, w.out, stride_, w.frames.data(), w.status.data());
         }
-        w0_ = first;
-        w1_ = last;
+        w.w0 = first;
+        w.w1 = last;
+    }
+    // waits for the read-ahead (if any); its window becomes valid or its error is dropped (the reader will meet it again)
+    void Settle() {
+        if (!ahead_.valid()) return;
+        try {
+            ahead_.get();
+            ahead_ok_ = true;
+        } catch (...) {
+            ahead_ok_ = false;
+        }
     }
     void NextPacket() {
         const size_t k = idx_;
-        if (lost_ != k && !(w0_ <= k && k < w1_)) DecodeWindow(k);
-        if (lost_ == k) throw ErrRead("reading sample " + std::to_string(k) + ": unexpected EOF");
-        const size_t j = k - w0_;
-        if (status_[j]) throw ErrDecode(status_[j], "decoding packet " + std::to_string(k) + ": " + StatusText(status_[j]));
-        buf_ = out_.data() + j * stride_;
-        buf_len_ = (size_t)frames_[j] * bpf_;
+        if (!win_[cur_].Holds(k)) {
+            Settle();
+            Window& other = win_[cur_ ^ 1u];
+            if (ahead_ok_ && other.Holds(k)) {
+                cur_ ^= 1u;
+            } else {  // the first window, a seek, or a read-ahead that failed: decode here (and let its error out)
+                DecodeWindow(win_[cur_], k);
+            }
+            ahead_ok_ = false;
+            // the window behind this one, while the caller drains this one
+            Window& c = win_[cur_];
+            if (c.lost == SIZE_MAX && c.w1 < Packets() && c.w1 > c.w0) {
+                Window* nxt = &win_[cur_ ^ 1u];
+                const size_t first = c.w1;
+                ahead_ = std::async(std::launch::async, [this, nxt, first] { DecodeWindow(*nxt, first); });
+            }
+        }
+        Window& w = win_[cur_];
+        if (w.lost == k) throw ErrRead("reading sample " + std::to_string(k) + ": unexpected EOF");
+        const size_t j = k - w.w0;
+        if (w.status[j]) throw ErrDecode(w.status[j], "decoding packet " + std::to_string(k) + ": " + StatusText(w.status[j]));
+        buf_ = w.out + j * stride_;
+        buf_len_ = (size_t)w.frames[j] * bpf_;
         buf_off_ = 0;
         ++idx_;
     }
@@ -167,14 +234,13 @@ private:
     const uint8_t* buf_ = nullptr;
     size_t buf_off_ = 0, buf_len_ = 0;
     bool eof_ = false;
-    size_t w0_ = 0, w1_ = 0, lost_ = SIZE_MAX;
-    std::vector<uint64_t> starts_;
-    std::vector<uint8_t> gather_, out_;
-    std::vector<uint32_t> frames_;
-    std::vector<int32_t> status_;
+    Window win_[2];
+    unsigned cur_ = 0;
+    std::future<void> ahead_;  // the read-ahead of win_[cur_ ^ 1]
+    bool ahead_ok_ = false;
 };
 
-inline std::unique_ptr<Decoder> NewDecoder(const uint8_t* file, size_t len, int device = 0, size_t window = 4096) {
+inline std::unique_ptr<Decoder> NewDecoder(const uint8_t* file, size_t len, int device = 0, size_t window = 1024) {
     return std::make_unique<Decoder>(file, len, device, window);
 }
 

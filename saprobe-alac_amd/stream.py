@@ -4,9 +4,11 @@ Same surface — NewDecoder, Format, Duration, Position, Seek, Read — and the 
 packet order, packet-aligned seeks, the error for packet k raised when the reader reaches packet k and again on
 every later Read. What differs is how the PCM gets made: instead of one DecodePacket per packet the decoder reads
 ahead — a window of packets goes through ONE batch decode on the GPU (`alacgpu_decode_batch`: gather, H2D, the
-kernels, D2H) and Read / Seek are served from the decoded window.
+kernels, D2H) and Read / Seek are served from the decoded window. While the caller drains window k a worker thread has
+window k + 1 decoded (the C call releases the GIL), as host/stream_decoder.hpp does.
 """
 import os
+import threading
 
 import numpy as np
 
@@ -34,7 +36,7 @@ def _as_buffer(source):
 class Decoder:
     """Streams decoded PCM from an ALAC M4A/MP4 source (decode.go:32-45). `window` = packets per batch decode."""
 
-    def __init__(self, source, device=0, window=4096):
+    def __init__(self, source, device=0, window=1024):
         self._data = _as_buffer(source)
         self._view = memoryview(self._data).cast("B") if not isinstance(self._data, np.ndarray) else memoryview(self._data)
         try:
@@ -60,6 +62,7 @@ class Decoder:
         self._w0 = self._w1 = 0          # decoded window: packets [w0, w1)
         self._w_out = self._w_frames = self._w_status = None
         self._w_read_err = None          # (packet index, message): a sample that lies outside the file
+        self._ahead = None               # (thread, box): the window behind the current one, being decoded
 
     # ---- decode.go:79-124 -------------------------------------------------------------------------------
     def Format(self):
@@ -85,16 +88,17 @@ class Decoder:
         return (self._idx * fl * 1_000_000_000 // sr) / 1e9
 
     # ---- the read-ahead window -------------------------------------------------------------------------------
-    def _decode_window(self, first):
+    def _decode(self, first):
+        """Packets [first, first + window) through one batch decode -> (w0, w1, out, frames, status, read_err)."""
         last = min(first + self._window, len(self._sizes))
         offs = self._offsets[first:last].astype(np.int64)
         sizes = self._sizes[first:last].astype(np.int64)
         n_file = len(self._view)
-        self._w_read_err = None
+        read_err = None
         bad = np.nonzero(offs + sizes > n_file)[0]
         if len(bad):  # decode.go:163-169: the seek or the ReadFull of that sample fails when the reader gets there
             k = int(bad[0])
-            self._w_read_err = (first + k, "reading sample %d: unexpected EOF" % (first + k))
+            read_err = (first + k, "reading sample %d: unexpected EOF" % (first + k))
             last = first + k
             offs, sizes = offs[:k], sizes[:k]
         n = last - first
@@ -107,11 +111,42 @@ class Decoder:
             blob = np.empty(int(starts[n]) + 1, np.uint8)
             for k in range(n):
                 blob[int(starts[k]):int(starts[k + 1])] = raw[int(offs[k]):int(offs[k] + sizes[k])]
+        out = frames = status = None
         if n:
             if blob.size == 0:
                 blob = np.zeros(1, np.uint8)  # only empty packets: the entry still wants a readable pointer
-            self._w_out, self._w_frames, self._w_status = self._dec.decode_batch(np.ascontiguousarray(blob), starts)
-        self._w0, self._w1 = first, last
+            out, frames, status = self._dec.decode_batch(np.ascontiguousarray(blob), starts)
+        return first, last, out, frames, status, read_err
+
+    def _install(self, w):
+        self._w0, self._w1, self._w_out, self._w_frames, self._w_status, self._w_read_err = w
+
+    def _settle(self):
+        """Waits for the read-ahead; -> its window, or None (none running, or it failed: the reader meets the error again)."""
+        if self._ahead is None:
+            return None
+        thread, box = self._ahead
+        thread.join()
+        self._ahead = None
+        return box.get("window")
+
+    def _decode_window(self, first):
+        w = self._settle()
+        if w is None or not (w[0] <= first < w[1] or (w[5] is not None and w[5][0] == first)):
+            w = self._decode(first)  # the first window, a seek, or a failed read-ahead (its error comes out here)
+        self._install(w)
+        if w[5] is None and w[0] < w[1] < len(self._sizes):  # the window behind this one, while the caller drains this one
+            box = {}
+
+            def work(start=w[1]):
+                try:
+                    box["window"] = self._decode(start)
+                except Exception:  # noqa: BLE001  (met again, synchronously, when the reader gets there)
+                    pass
+
+            thread = threading.Thread(target=work, daemon=True)
+            thread.start()
+            self._ahead = (thread, box)
 
     def _next_packet(self):
         """PCM of packet self._idx (decode.go:157-187); raises what the reference returns from Read."""
@@ -170,6 +205,7 @@ class Decoder:
         return b"".join(parts)
 
     def close(self):
+        self._settle()
         self._dec.close()
 
     def __enter__(self):
