@@ -161,6 +161,15 @@ int alacgpu_decode_batch(alacgpu_decoder* dec, const uint8_t* blob, size_t blob_
                          size_t n_packets, uint8_t* out, size_t out_stride,
                          uint32_t* frames_out, int32_t* status);
 
+/* The same decode on a thread of the library's own: _start returns at once, _wait blocks until the decode is done and
+ * returns what alacgpu_decode_batch would have (its error text becomes the waiting thread's alacgpu_last_error). One
+ * decode in flight per handle; nothing else may be called on the handle in between (alacgpu_destroy waits by itself), and
+ * all buffers stay the caller's to keep alive and untouched until _wait returns. What a read-ahead file decoder needs:
+ * window k + 1 is decoded while the caller drains window k (host/stream_decoder.hpp, stream.py, go/alacgpu_decoder.go). */
+int alacgpu_decode_batch_start(alacgpu_decoder* dec, const uint8_t* blob, size_t blob_bytes, const uint64_t* offsets,
+                               size_t n_packets, uint8_t* out, size_t out_stride, uint32_t* frames_out, int32_t* status);
+int alacgpu_decode_batch_wait(alacgpu_decoder* dec);
+
 /*
  * DecodePackets, device-resident (the benchmark path). All pointers are device pointers on the handle's device.
  * Packet i is d_blob[d_offsets[i] .. +d_sizes[i]); d_sizes may be NULL, then d_offsets has n_packets+1 entries and

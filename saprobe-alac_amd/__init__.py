@@ -214,6 +214,10 @@ _EXPORTS = {
     "alacgpu_decode_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                             ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                             ctypes.c_void_p]),
+    "alacgpu_decode_batch_start": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                  ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                  ctypes.c_void_p]),
+    "alacgpu_decode_batch_wait": (ctypes.c_int, [ctypes.c_void_p]),
     "alacgpu_decode_batch_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
@@ -370,6 +374,27 @@ class PacketDecoder:
                                                   out.ctypes.data, stride, frames.ctypes.data, status.ctypes.data))
         return out, frames, status
 
+    def decode_batch_start(self, blob, offsets, out_stride=None):
+        """alacgpu_decode_batch_start: the same decode on a thread of the library's own (no Python thread, no GIL to fight
+        for). -> a token for decode_batch_wait; nothing else may be called on this decoder until then."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        stride = out_stride or self.frame_bytes
+        out = np.empty((max(n, 0), stride), dtype=np.uint8)
+        frames = np.zeros(max(n, 0), dtype=np.uint32)
+        status = np.zeros(max(n, 0), dtype=np.int32)
+        if n > 0:
+            _check(self._lib.alacgpu_decode_batch_start(self._h, blob.ctypes.data, blob.size, offsets.ctypes.data, n,
+                                                        out.ctypes.data, stride, frames.ctypes.data, status.ctypes.data))
+        return (blob, offsets, out, frames, status, n > 0)  # the token keeps every buffer alive
+
+    def decode_batch_wait(self, token):
+        """-> (out, frames, status) of the decode decode_batch_start began; raises what decode_batch would have."""
+        if token[5]:
+            _check(self._lib.alacgpu_decode_batch_wait(self._h))
+        return token[2], token[3], token[4]
+
     def decode_batch_device(self, d_blob, blob_bytes, d_offsets, d_sizes, n, d_out, out_stride, d_frames, d_status,
                             sync=True):
         """alacgpu_decode_batch_device: raw device pointers (ints), e.g. torch tensors' data_ptr(); blob_bytes =
@@ -423,7 +448,7 @@ def NewPacketDecoder(config, device=0):
     return PacketDecoder(config, device)
 
 
-def NewDecoder(source, device=0, window=4096):
+def NewDecoder(source, device=0, window=1024):
     """NewDecoder (decode.go:50-76): streaming façade over the batch path, see stream.py."""
     from . import stream
     return stream.NewDecoder(source, device=device, window=window)

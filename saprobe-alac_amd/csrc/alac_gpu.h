@@ -444,8 +444,11 @@ struct GpuWave {
         __syncthreads();
     }
     /* rows of 64 cells whatever ppw is: a constant stride lets unrolled steps address their rows by immediate
-     * offsets from one base, and every lane (with or without a packet) owns a column */
-    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + ((size_t)i * kWave + lane); }
+     * offsets from one base. A lane with a packet slot owns cell `lane`; in a narrow wave (ppw < 64: small batches) the
+     * lanes beyond ppw share cell ppw of the row, a dummy: they store without a branch like everyone else, but one dword
+     * instead of 64 - ppw of them (round 3: the dead lanes of BASELINE config b's sixteen-lane waves wrote three quarters
+     * of every row: 6.2 x the algorithmic traffic). */
+    ALAC_DEV int32_t* u_row(uint32_t i) const { return u_tile + ((size_t)i * kWave + (ppw < kWave ? (lane < ppw ? lane : ppw) : lane)); }
     ALAC_DEV int32_t* g_slot(uint32_t k) const { return g_tile + (size_t)k * ppw; }
 };
 

@@ -216,6 +216,9 @@ struct alacgpu_decoder {
     size_t chunk_bytes;                                      /* host entry: target bytes (in + out) per chunk */
     uint32_t lanes_min;                                      /* PairArgs::lanes_min; above 16: no second predictor wave for any key */
     int side;                                                /* launch(): irregular packets on s_side (ALACGPU_SIDE: 0 never, 1 up to 6 x CUs wave slots, 2 always: the default) */
+    std::thread* ahead;                                      /* alacgpu_decode_batch_start: the decode in flight (nullptr: none) */
+    int ahead_rc;
+    char ahead_err[512];
     size_t last_n;                                           /* the last device decode: packets, packets per wave slot, PairArgs::cap */
     uint32_t last_ppw, last_cap;
 };
@@ -572,6 +575,9 @@ void configure(alacgpu_decoder* d, const alacgpu_config* cfg, int bps) {
     d->dev_cfg = alac::DevCfg{cfg->frame_length, cfg->bit_depth, cfg->num_channels, cfg->pb, cfg->mb, cfg->kb,
                               (uint32_t)bps, 0u};
     d->launches = 0;
+    d->ahead = nullptr;
+    d->ahead_rc = ALACGPU_E_OK;
+    d->ahead_err[0] = 0;
     d->last_n = 0;
     d->last_ppw = d->last_cap = 0;
     d->il_threads = 64;
@@ -590,6 +596,8 @@ void configure(alacgpu_decoder* d, const alacgpu_config* cfg, int bps) {
     }
 }
 } /* namespace */
+
+static int settle_ahead(alacgpu_decoder* d);
 
 extern "C" {
 
@@ -672,6 +680,7 @@ int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out)
 
 void alacgpu_destroy(alacgpu_decoder* d) {
     if (!d) return;
+    (void)settle_ahead(d);
     (void)hipSetDevice(d->device);
     /* nothing of this handle's last call may still be running when its belongings go to the next owner */
     bool ok = hipStreamSynchronize(d->stream) == hipSuccess && hipStreamSynchronize(d->s_in) == hipSuccess &&
@@ -777,6 +786,40 @@ int alacgpu_reserve(alacgpu_decoder* d, size_t n) {
     if (!d) return ALACGPU_E_ARG;
     HIP_TRY(hipSetDevice(d->device));
     return reserve_workspace(d, n, pick_ppw(n));
+}
+
+/* the decode alacgpu_decode_batch_start put on a thread of its own, if any: wait for it and take over its result */
+static int settle_ahead(alacgpu_decoder* d) {
+    if (!d->ahead) return ALACGPU_E_OK;
+    d->ahead->join();
+    delete d->ahead;
+    d->ahead = nullptr;
+    if (d->ahead_rc != ALACGPU_E_OK) set_err("%s", d->ahead_err);
+    return d->ahead_rc;
+}
+
+int alacgpu_decode_batch_start(alacgpu_decoder* d, const uint8_t* blob, size_t blob_bytes, const uint64_t* offsets, size_t n,
+                               uint8_t* out, size_t out_stride, uint32_t* frames_out, int32_t* status) {
+    if (!d) return ALACGPU_E_ARG;
+    if (d->ahead) {
+        set_err("a decode started with alacgpu_decode_batch_start is still in flight: alacgpu_decode_batch_wait first");
+        return ALACGPU_E_ARG;
+    }
+    d->ahead_rc = ALACGPU_E_OK;
+    d->ahead = new (std::nothrow) std::thread([=] {
+        d->ahead_rc = alacgpu_decode_batch(d, blob, blob_bytes, offsets, n, out, out_stride, frames_out, status);
+        if (d->ahead_rc != ALACGPU_E_OK) snprintf(d->ahead_err, sizeof(d->ahead_err), "%s", alacgpu_last_error());
+    });
+    if (!d->ahead) {
+        set_err("out of memory");
+        return ALACGPU_E_ARG;
+    }
+    return ALACGPU_E_OK;
+}
+
+int alacgpu_decode_batch_wait(alacgpu_decoder* d) {
+    if (!d) return ALACGPU_E_ARG;
+    return settle_ahead(d);
 }
 
 int alacgpu_decode_batch_device(alacgpu_decoder* d, const uint8_t* d_blob, size_t blob_bytes, const uint64_t* d_offsets,

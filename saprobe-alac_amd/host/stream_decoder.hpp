@@ -123,26 +123,34 @@ private:
     // one decoded window: packets [w0, w1); `lost`: the first sample behind it that lies outside the file (decode.go:163-169)
     struct Window {
         size_t w0 = 0, w1 = 0, lost = SIZE_MAX;
-        uint8_t* out = nullptr;  // pinned when the runtime grants it
+        // ONE pinned block (when the runtime grants it): [PCM n x stride | frames n x u32 | status n x i32]. The library
+        // transfers into caller memory in place only when all three are pinned.
+        uint8_t* block = nullptr;
         size_t cap = 0;
         bool pinned = false;
+        uint8_t* out = nullptr;
+        uint32_t* frames = nullptr;
+        int32_t* status = nullptr;
         std::vector<uint64_t> starts;
         std::vector<uint8_t> gather;
-        std::vector<uint32_t> frames;
-        std::vector<int32_t> status;
         bool Holds(size_t k) const { return (w0 <= k && k < w1) || lost == k; }
-        void Reserve(size_t bytes) {
-            if (bytes <= cap) return;
-            Free();
-            out = static_cast<uint8_t*>(alacgpu_host_alloc(bytes));
-            pinned = out != nullptr;
-            if (!out) out = static_cast<uint8_t*>(::operator new(bytes));  // pageable: the library stages the copy
-            cap = bytes;
+        void Reserve(size_t n, size_t stride) {
+            const size_t pcm = (n * stride + 15u) & ~(size_t)15u, bytes = pcm + n * 8u;
+            if (bytes > cap) {
+                Free();
+                block = static_cast<uint8_t*>(alacgpu_host_alloc(bytes));
+                pinned = block != nullptr;
+                if (!block) block = static_cast<uint8_t*>(::operator new(bytes));  // pageable: the library stages the copies
+                cap = bytes;
+            }
+            out = block;
+            frames = reinterpret_cast<uint32_t*>(block + pcm);
+            status = reinterpret_cast<int32_t*>(block + pcm + n * 4u);
         }
         void Free() {
-            if (out && pinned) alacgpu_host_free(out);
-            else if (out) ::operator delete(out);
-            out = nullptr;
+            if (block && pinned) alacgpu_host_free(block);
+            else if (block) ::operator delete(block);
+            block = nullptr;
             cap = 0;
         }
     };
@@ -177,10 +185,8 @@ private:
                 blob = &none;
                 blob_bytes = 0;
             }
-            w.Reserve(n * stride_);
-            w.frames.resize(n);
-            w.status.resize(n);
-            dec_->DecodePackets(blob, blob_bytes, w.starts.data(), n, w.out, stride_, w.frames.data(), w.status.data());
+            w.Reserve(n, stride_);
+            dec_->DecodePackets(blob, blob_bytes, w.starts.data(), n, w.out, stride_, w.frames, w.status);
         }
         w.w0 = first;
         w.w1 = last;

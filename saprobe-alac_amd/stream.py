@@ -4,11 +4,11 @@ Same surface — NewDecoder, Format, Duration, Position, Seek, Read — and the 
 packet order, packet-aligned seeks, the error for packet k raised when the reader reaches packet k and again on
 every later Read. What differs is how the PCM gets made: instead of one DecodePacket per packet the decoder reads
 ahead — a window of packets goes through ONE batch decode on the GPU (`alacgpu_decode_batch`: gather, H2D, the
-kernels, D2H) and Read / Seek are served from the decoded window. While the caller drains window k a worker thread has
-window k + 1 decoded (the C call releases the GIL), as host/stream_decoder.hpp does.
+kernels, D2H) and Read / Seek are served from the decoded window. While the caller drains window k the library has
+window k + 1 decoded on a thread of its own (alacgpu_decode_batch_start / _wait: a Python thread would spend the time
+waiting for the interpreter lock the draining loop holds), as host/stream_decoder.hpp does.
 """
 import os
-import threading
 
 import numpy as np
 
@@ -88,8 +88,8 @@ class Decoder:
         return (self._idx * fl * 1_000_000_000 // sr) / 1e9
 
     # ---- the read-ahead window -------------------------------------------------------------------------------
-    def _decode(self, first):
-        """Packets [first, first + window) through one batch decode -> (w0, w1, out, frames, status, read_err)."""
+    def _prepare(self, first):
+        """Packets [first, first + window): -> (w0, w1, blob, starts, read_err), nothing decoded yet."""
         last = min(first + self._window, len(self._sizes))
         offs = self._offsets[first:last].astype(np.int64)
         sizes = self._sizes[first:last].astype(np.int64)
@@ -111,12 +111,17 @@ class Decoder:
             blob = np.empty(int(starts[n]) + 1, np.uint8)
             for k in range(n):
                 blob[int(starts[k]):int(starts[k + 1])] = raw[int(offs[k]):int(offs[k] + sizes[k])]
+        if n and blob.size == 0:
+            blob = np.zeros(1, np.uint8)  # only empty packets: the entry still wants a readable pointer
+        return first, last, blob, starts, read_err
+
+    def _decode(self, first):
+        """-> (w0, w1, out, frames, status, read_err): one batch decode, here and now."""
+        w0, w1, blob, starts, read_err = self._prepare(first)
         out = frames = status = None
-        if n:
-            if blob.size == 0:
-                blob = np.zeros(1, np.uint8)  # only empty packets: the entry still wants a readable pointer
-            out, frames, status = self._dec.decode_batch(np.ascontiguousarray(blob), starts)
-        return first, last, out, frames, status, read_err
+        if w1 > w0:
+            out, frames, status = self._dec.decode_batch(blob, starts)
+        return w0, w1, out, frames, status, read_err
 
     def _install(self, w):
         self._w0, self._w1, self._w_out, self._w_frames, self._w_status, self._w_read_err = w
@@ -125,10 +130,13 @@ class Decoder:
         """Waits for the read-ahead; -> its window, or None (none running, or it failed: the reader meets the error again)."""
         if self._ahead is None:
             return None
-        thread, box = self._ahead
-        thread.join()
+        (w0, w1, read_err), token = self._ahead
         self._ahead = None
-        return box.get("window")
+        try:
+            out, frames, status = self._dec.decode_batch_wait(token)
+        except AlacError:
+            return None
+        return w0, w1, out, frames, status, read_err
 
     def _decode_window(self, first):
         w = self._settle()
@@ -136,17 +144,9 @@ class Decoder:
             w = self._decode(first)  # the first window, a seek, or a failed read-ahead (its error comes out here)
         self._install(w)
         if w[5] is None and w[0] < w[1] < len(self._sizes):  # the window behind this one, while the caller drains this one
-            box = {}
-
-            def work(start=w[1]):
-                try:
-                    box["window"] = self._decode(start)
-                except Exception:  # noqa: BLE001  (met again, synchronously, when the reader gets there)
-                    pass
-
-            thread = threading.Thread(target=work, daemon=True)
-            thread.start()
-            self._ahead = (thread, box)
+            n0, n1, blob, starts, read_err = self._prepare(w[1])
+            if n1 > n0:
+                self._ahead = ((n0, n1, read_err), self._dec.decode_batch_start(blob, starts))
 
     def _next_packet(self):
         """PCM of packet self._idx (decode.go:157-187); raises what the reference returns from Read."""

@@ -77,6 +77,8 @@ int main(int argc, char** argv) {
         fns[i++] = (void (*)(void))alacgpu_trim;
         fns[i++] = (void (*)(void))alacgpu_pair_placement;
         fns[i++] = (void (*)(void))alacgpu_last_dispatch;
+        fns[i++] = (void (*)(void))alacgpu_decode_batch_start;
+        fns[i++] = (void (*)(void))alacgpu_decode_batch_wait;
         fns[i++] = (void (*)(void))alacgpu_host_alloc;
         fns[i++] = (void (*)(void))alacgpu_host_free;
         while (i--)

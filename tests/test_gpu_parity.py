@@ -264,6 +264,26 @@ def test_long_frames_match_oracle(pkg, oracle, synth, helpers, gpu_decoder_facto
                 helpers.assert_same_decode(cfg, ref, _gpu_decode(dec, blob, offs, sizes), bpf, "%d frames, damaged" % fl)
 
 
+@pytest.mark.parametrize("depth,ch", [(32, 1), (24, 2), (24, 1), (20, 1)])
+def test_runs_of_escape_codes_up_to_a_truncation_point(pkg, oracle, synth, helpers, gpu_decoder_factory, depth, ch):
+    """The GPU twin of tests/test_lane_logic.py's test of the same name: escape code after escape code (24 / 32-bit
+    streams without shift bytes: up to 41 bits a step, inside the lean step) in packets cut at every byte of their last
+    stretch, full 64-lane waves of them; status words and the frames in front are the oracle's (golomb.go:168,86-108)."""
+    fl = 96
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    b = synth.gen_batch(cfg, 12, profile=synth.PROFILE_MUSIC_NOSHIFT, threads=4)
+    packets = []
+    for i in range(b.n):
+        p = b.packet(i)
+        packets += [p[:k] for k in range(max(1, len(p) - 90), len(p) + 1)]
+    blob, offs, sizes = helpers.pack_packets(packets)
+    ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=8)
+    assert len(np.unique(ref[2])) >= 2
+    with gpu_decoder_factory(cfg) as dec:
+        helpers.assert_same_decode(cfg, ref, _gpu_decode(dec, blob, offs, sizes), bpf, "truncated escape runs")
+
+
 def test_ragged_and_empty_batches(pkg, oracle, synth, helpers, gpu_decoder_factory):
     cfg = oracle.make_config(512, 16, 2)
     with gpu_decoder_factory(cfg) as dec:

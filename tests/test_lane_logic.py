@@ -89,6 +89,28 @@ def test_lane_matches_oracle_on_other_cookie_bytes(oracle, synth, lane_sim, help
                                                "loud, pb %d variant %d" % (pb, variant))
 
 
+@pytest.mark.parametrize("depth,ch", [(32, 1), (24, 2), (24, 1), (20, 1)])
+def test_runs_of_escape_codes_up_to_a_truncation_point(oracle, synth, lane_sim, helpers, depth, ch):
+    """Streams without shift bytes at 24 / 32 bits are escape code after escape code (9 + chanBits = up to 41 bits each,
+    taken inside the lean step: alac_regular.h: gol_step, ESC); the lean step's bounds live in `near`, which is refreshed
+    every eight steps for the GOL_REACH = 8 x 41 bits a lane can move in between. Packets cut at every byte of their last
+    stretch: the status (overrun where the reference's loop test fails, malformed where getStreamBits would read outside,
+    golomb.go:168,86-108) and the frames in front must be the oracle's."""
+    fl = 96
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    b = synth.gen_batch(cfg, 6, profile=synth.PROFILE_MUSIC_NOSHIFT, threads=2)
+    packets = []
+    for i in range(b.n):
+        p = b.packet(i)
+        packets += [p[:k] for k in range(max(1, len(p) - 90), len(p) + 1)]
+    blob, offs, sizes = helpers.pack_packets(packets)
+    ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=4)
+    assert len(np.unique(ref[2])) >= 2
+    for variant in (-1, 3):
+        helpers.assert_same_decode(cfg, ref, lane_sim(cfg, blob, offs, sizes, variant=variant), bpf, "variant %d" % variant)
+
+
 @pytest.mark.parametrize("depth,ch,fl", [(16, 2, 33), (16, 2, 47), (16, 2, 1000), (16, 1, 4095), (24, 2, 129),
                                          (20, 1, 65), (32, 2, 200), (16, 2, 4097)])
 def test_wave_pair_chunk_tails(oracle, synth, lane_sim, helpers, depth, ch, fl):

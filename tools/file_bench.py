@@ -68,6 +68,8 @@ def main():
                 ok = ok and got == total and h.digest() == exp.digest()
         res["python_ms_median"] = round(float(np.median(times)) * 1e3, 2)
         res["python_ms_best"] = round(min(times) * 1e3, 2)
+        if os.environ.get("FILE_BENCH_VERBOSE"):
+            res["python_ms_all"] = [round(t * 1e3, 2) for t in times]
         # ---- C++ façade
         buf = (ctypes.c_uint8 * len(data)).from_buffer_copy(data)
         out = (ctypes.c_uint8 * 65536)()
