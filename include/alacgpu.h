@@ -224,6 +224,7 @@ typedef struct alacgpu_dispatch {
     uint32_t gated;              /* 1: the gated twin took the narrow slots */
     uint32_t lanes_per_packet;   /* 2 / 4: predictor waves on that many lanes per packet for the long predictors; 0: none */
     char narrow_kernel[32], wide_kernel[32], irregular_kernels[96]; /* "" when the class is empty */
+    uint32_t workgroups_per_cu;  /* four-wave kernels: 4 or 5 of their workgroups share a CU (the LDS footprint of the launch that worked); 0: gated twin / none */
 } alacgpu_dispatch;
 int alacgpu_last_dispatch(alacgpu_decoder* dec, alacgpu_dispatch* out);
 /* Placement relies on the gfx950 layout of two hardware registers read with s_getreg_b32: HW_ID (SIMD [5:4], CU [11:8],

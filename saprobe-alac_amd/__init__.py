@@ -196,7 +196,7 @@ class Dispatch(ctypes.Structure):
     _fields_ = [("packets_per_slot", ctypes.c_uint32), ("slots", ctypes.c_uint32), ("irregular_slots", ctypes.c_uint32),
                 ("wide_slots", ctypes.c_uint32), ("narrow_slots", ctypes.c_uint32), ("keys", ctypes.c_uint32),
                 ("gated", ctypes.c_uint32), ("lanes_per_packet", ctypes.c_uint32), ("narrow_kernel", ctypes.c_char * 32),
-                ("wide_kernel", ctypes.c_char * 32), ("irregular_kernels", ctypes.c_char * 96)]
+                ("wide_kernel", ctypes.c_char * 32), ("irregular_kernels", ctypes.c_char * 96), ("workgroups_per_cu", ctypes.c_uint32)]
 
 
 _EXPORTS = {
@@ -437,6 +437,7 @@ class PacketDecoder:
         _check(self._lib.alacgpu_last_dispatch(self._h, ctypes.byref(d)))
         out = {k: int(getattr(d, k)) for k, _ in Dispatch._fields_[:8]}
         out.update({k: getattr(d, k).decode() for k in ("narrow_kernel", "wide_kernel", "irregular_kernels")})
+        out["workgroups_per_cu"] = int(d.workgroups_per_cu)
         return out
 
     def synchronize(self):

@@ -217,8 +217,16 @@ constexpr uint32_t kTimingSlots = 64;
 #ifndef ALAC_LDS_RING
 #define ALAC_LDS_RING 32
 #endif
+#ifndef ALAC_LDS_FLUSH
+#define ALAC_LDS_FLUSH (ALAC_LDS_ROWS / 2)
+#endif
 constexpr uint32_t kRing = ALAC_LDS_ROWS;                   /* dwords of PCM a lane row holds (two flush chunks) */
-constexpr uint32_t kFlush = kRing / 2;                      /* dwords per lane and flush */
+/* dwords per lane and flush. Half a row where a writer pushes groups that straddle the flush boundary (six dwords per four
+ * 3-byte frames); a WHOLE row (ALAC_LDS_FLUSH = ALAC_LDS_ROWS = 32) where every push is a power of two of dwords that ends
+ * on the boundary and st_step() follows every group: the row is written out the moment it is full, as whole 128-byte
+ * lines, from half the LDS (k_dec16q.hip, k_dec32q.hip) */
+constexpr uint32_t kFlush = ALAC_LDS_FLUSH;
+static_assert(kFlush <= kRing && kRing % 4 == 0 && (kFlush == 16 || kFlush == 32), "the stager flushes 64- or 128-byte pieces of its rows");
 constexpr uint32_t kRowStride = kRing + 1;                  /* odd stride = conflict-free column access */
 constexpr uint32_t kFallbackSlots = 64;
 constexpr uint32_t kRingDw = ALAC_LDS_RING;                 /* bitstream ring, dwords per lane */
@@ -298,33 +306,47 @@ struct GpuWave {
         /* every lane holds the maximum: hand it back as a scalar, so loops bounded by it are uniform */
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     }
+    /* position in the lane's stager row of the next dword pushed / the next one flushed: wcnt, flushed modulo kRing. Rows of
+     * 48 dwords (k_dec24q.hip: eight six-dword groups of the 3-byte pair writer, so that no group straddles the end of the
+     * row; whole 128-byte lines from 12 KB of rows) keep the two positions in registers of their own */
+    static constexpr bool kRingPow2 = (kRing & (kRing - 1u)) == 0u;
+    uint32_t wpos, fpos;
+    ALAC_DEV static uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
+    ALAC_DEV static uint32_t st_wrap(uint32_t x) { return kRingPow2 ? (x & (kRing - 1u)) : umin_(x, x - kRing); } /* x < 2 kRing */
+    ALAC_DEV uint32_t st_pos() const { return kRingPow2 ? (wcnt & (kRing - 1u)) : wpos; }
+    ALAC_DEV void st_adv(uint32_t n) {
+        wcnt += n;
+        if (!kRingPow2) wpos = st_wrap(wpos + n);
+    }
     ALAC_DEV void st_begin(uint8_t* out) {
         my_out = out;
         s_optr[lane] = (unsigned long long)reinterpret_cast<uintptr_t>(out);
         wcnt = flushed = 0;
+        wpos = fpos = 0;
     }
     ALAC_DEV void st_push(uint32_t v) {
-        s_rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
-        ++wcnt;
+        s_rows[lane * kRowStride + st_pos()] = v;
+        st_adv(1u);
     }
     /* branch-free form: a lane that is not `on` rewrites its next free slot and does not advance */
     ALAC_DEV void st_push_if(uint32_t v, bool on) {
-        s_rows[lane * kRowStride + (wcnt & (kRing - 1u))] = v;
-        wcnt += on ? 1u : 0u;
+        s_rows[lane * kRowStride + st_pos()] = v;
+        st_adv(on ? 1u : 0u);
     }
     /* Groups of un = 4 or 8 dwords, one per step, from lanes that either keep all of them or none (alac_duo.h: whole chunks
      * inside or behind the lane's frames): the group's place in the row is worked out once, the eight stores carry
      * immediate offsets. A lane that keeps them (`inc` = un) stands at a multiple of un (it has pushed one dword per
      * frame); one that does not has already written its tail out (st_finish) or never had anything: it scribbles over
-     * eight dwords of its own row that nobody will look at. */
-    ALAC_DEV uint32_t st_group_base(uint32_t un) const { return lane * kRowStride + (wcnt & (kRing - un)); }
+     * eight dwords of its own row that nobody will look at. (16-bit pairs written by the predictor wave: rows of 32 / 64.) */
+    ALAC_DEV uint32_t st_group_base(uint32_t un) const { return lane * kRowStride + (kRingPow2 ? (wcnt & (kRing - un)) : wpos); }
     ALAC_DEV void st_put(uint32_t base, uint32_t j, uint32_t v, uint32_t) { s_rows[base + j] = v; }
-    ALAC_DEV void st_advance(uint32_t n) { wcnt += n; }
-    /* six dwords at once (four 24-bit stereo frames): straight on from the lane's position; the one group in ten
-     * that crosses the end of the ring (the same one for every lane that is still going) wraps dword by dword */
+    ALAC_DEV void st_advance(uint32_t n) { st_adv(n); }
+    /* six dwords at once (four 24-bit stereo frames): straight on from the lane's position; a group that crosses the end of
+     * the row (rows of 32 / 64: one in five / ten, the same one for every lane that is still going; rows of 48: none while the
+     * lane pushes whole groups) wraps dword by dword */
     /* (all six are stored; the lane's position moves on by `count`) */
     ALAC_DEV void st_push6_n(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t d4, uint32_t d5, uint32_t count) {
-        const uint32_t pos = wcnt & (kRing - 1u);
+        const uint32_t pos = st_pos();
         uint32_t* row = s_rows + lane * kRowStride;
         if (pos <= kRing - 6u) {
             uint32_t* r = row + pos;
@@ -336,13 +358,13 @@ struct GpuWave {
             r[5] = d5;
         } else {
             row[pos] = d0;
-            row[(pos + 1u) & (kRing - 1u)] = d1;
-            row[(pos + 2u) & (kRing - 1u)] = d2;
-            row[(pos + 3u) & (kRing - 1u)] = d3;
-            row[(pos + 4u) & (kRing - 1u)] = d4;
-            row[(pos + 5u) & (kRing - 1u)] = d5;
+            row[st_wrap(pos + 1u)] = d1;
+            row[st_wrap(pos + 2u)] = d2;
+            row[st_wrap(pos + 3u)] = d3;
+            row[st_wrap(pos + 4u)] = d4;
+            row[st_wrap(pos + 5u)] = d5;
         }
-        wcnt += count; /* the lane keeps the first `count` of them (a partial frame ends inside the group) */
+        st_adv(count); /* the lane keeps the first `count` of them (a partial frame ends inside the group) */
     }
     /* bytes of the last, incomplete dword of the stream (after every dword pushed so far) */
     ALAC_DEV void st_tail(uint64_t acc, uint32_t nbytes) {
@@ -360,13 +382,14 @@ struct GpuWave {
         __builtin_amdgcn_wave_barrier();
         const int first = __ffsll((long long)mask) - 1;
         const uint32_t fl = (uint32_t)__shfl((int)flushed, first, 64);
-        const uint32_t col0 = fl & (kRing - 1u);
+        const uint32_t col0 = kRingPow2 ? (fl & (kRing - 1u)) : (uint32_t)__shfl((int)fpos, first, 64);
         const uint32_t piece = lane & (LPP - 1u);
         const uint32_t groups = (ppw + PPI - 1u) / PPI;
+        const uint32_t col = st_wrap(col0 + piece * 4u); /* kRing and col0 are multiples of four: a piece never straddles the end */
         for (uint32_t k = 0; k < groups; ++k) {
             const uint32_t q = PPI * k + lane / LPP;
             if ((mask >> q) & 1ull) {
-                const uint32_t* r = s_rows + q * kRowStride + col0 + piece * 4u;
+                const uint32_t* r = s_rows + q * kRowStride + col;
                 const uint4 v = make_uint4(r[0], r[1], r[2], r[3]);
                 uint8_t* dst = reinterpret_cast<uint8_t*>((uintptr_t)s_optr[q]) + ((size_t)fl + piece * 4u) * 4u;
                 /* the address came through LDS as an integer: name the global address space, or it is a flat store */
@@ -374,12 +397,19 @@ struct GpuWave {
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (full) flushed += kFlush;
+        if (full) {
+            flushed += kFlush;
+            if (!kRingPow2) fpos = st_wrap(fpos + kFlush);
+        }
     }
     ALAC_DEV uint32_t st_finish() {
-        for (uint32_t w = flushed; w < wcnt; ++w)
-            *reinterpret_cast<uint32_t*>(my_out + (size_t)w * 4u) = s_rows[lane * kRowStride + (w & (kRing - 1u))];
+        uint32_t c = kRingPow2 ? 0u : fpos;
+        for (uint32_t w = flushed; w < wcnt; ++w) {
+            *reinterpret_cast<uint32_t*>(my_out + (size_t)w * 4u) = s_rows[lane * kRowStride + (kRingPow2 ? (w & (kRing - 1u)) : c)];
+            if (!kRingPow2) c = st_wrap(c + 1u);
+        }
         flushed = wcnt;
+        if (!kRingPow2) fpos = wpos;
         return wcnt;
     }
     /* bitstream ring of the entropy wave: kRingDw dwords per lane, slot-major (kRingSlots) */
@@ -494,40 +524,50 @@ __global__ void alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, 
                             const alac::PktDesc* __restrict__ pd, uint8_t* __restrict__ out, uint64_t out_stride,
                             uint32_t* __restrict__ frames_out, int32_t* __restrict__ status, int32_t* __restrict__ scratch_u,
                             int32_t* __restrict__ scratch_g, uint32_t ppw);
-/* ---- which kernel takes the narrow regular wave slots of a batch (k_decode_body.inc; evaluated on the device, where the
- * number of items is known, and again on the host for alacgpu_last_dispatch) ---- */
+/* ---- which kernel takes the narrow regular wave slots of a batch, and in which shape (k_decode_body.inc; evaluated on the
+ * device, where the number of items is known, and again on the host for alacgpu_last_dispatch) ----
+ * FOUR-WAVE WORKGROUPS PER CU (round 4). A four-wave workgroup is three waves a few microseconds after it started (the spare
+ * wave exits at once on a full device), so by registers a CU holds FIVE of them: four leave 3 waves x 120 registers on every
+ * SIMD, a fifth workgroup's four waves find 152 free registers on each, and after its spare wave has gone the SIMDs hold
+ * 4 / 4 / 4 / 3 waves and no sixth fits. What decided was LDS: 34 KB per workgroup (four per CU). With <= 30 KB of static
+ * LDS (stager rows of 32 or 48 dwords) the SAME kernel is launched with a dynamic-LDS pad up to 34 KB ("fit 4") or without
+ * ("fit 5"), both over the whole grid when the host's upper bound of the slot count allows five; decode_mode() — on the
+ * device, from the plan's count of narrow regular wave slots — says which launch works, the others' workgroups exit at once.
+ * Four per CU stay the rule: up to 4 x CUs slots the dispatcher then spreads them exactly evenly, and a CU
+ * with five is 1.38 x slower than one with four (its SIMDs hold 4 / 4 / 4 / 3 waves instead of 3 each, and issue is what
+ * the kernel is bound by). Five pay (profiles/r04_final/fit_sweep.txt; q = slots per CU):
+ *   4 < q <= 5   a round of five instead of four and a nearly empty one (24-bit 81 920 packets 4.16 -> 3.35 ms, 32-bit
+ *                7.11 -> 4.78; 16-bit 3.18 -> 2.95, where the gated pairs of k_dec16g.hip are as fast or faster and keep the batch);
+ *   q > 7        the dispatcher refills a CU workgroup by workgroup, and with five resident the tail of one "round" overlaps
+ *                the start of the next (16-bit 131 072 packets 4.55 -> 4.24 ms, 163 840 5.37 -> 5.21; 24-bit 131 072 6.42 -> 5.25).
+ * Between (5 < q <= 7) four per CU win (16-bit 114 688 packets 3.67 against 3.89 ms, 24-bit 98 304 4.52 against 4.64). */
+constexpr uint32_t kModeFit4 = 4u, kModeFit5 = 5u, kModeGated = 6u;
+/* cap: pairs per CU the width's gated twin holds (0: it has none); force (ALACGPU_FIT): 4 / 5 for every batch, no gated twin */
+constexpr __host__ __device__ __forceinline__ uint32_t decode_mode(uint32_t items, uint32_t n_cu, uint32_t cap, uint32_t force) {
+    if (force == kModeFit4 || force == kModeFit5) return force;
+    if (items <= 4u * n_cu) return kModeFit4;
+    if (items <= 5u * n_cu) return cap >= 5u ? kModeGated : kModeFit5;
+    if (items <= 6u * n_cu && cap >= 6u) return kModeGated;
+    return items <= 7u * n_cu ? kModeFit4 : kModeFit5;
+}
+/* pairs per CU the gated twin admits (k_decode_body.inc: the gate): as few as hold the batch at once */
 constexpr __host__ __device__ __forceinline__ uint32_t pair_quota(uint32_t items, uint32_t n_cu, uint32_t cap) {
-    /* relative duration of a round with k workgroups on every CU (measured at the end of round 3, 16-bit stereo,
-     * 4096-frame packets: four-wave workgroups 1.54 2.04 2.10 2.17 ms for k = 1..4, gated pairs 2.87 3.27 ms for 5 and 6);
-     * beyond six nothing is gained (VALU issue is saturated). A heuristic: either choice decodes the same bytes. */
-    const uint32_t t[7] = {0u, 154u, 204u, 210u, 217u, 287u, 327u};
-    uint32_t best = 1u, best_cost = 0xffffffffu;
-    for (uint32_t k = 1u; k <= 6u && k <= cap; ++k) {
-        const uint32_t rounds = (items + k * n_cu - 1u) / (k * n_cu);
-        const uint32_t cost = rounds * t[k];
-        if (cost < best_cost) {
-            best_cost = cost;
-            best = k;
-        }
-    }
-    return best;
+    const uint32_t need = (items + n_cu - 1u) / n_cu;
+    return need < 5u ? 5u : need < cap ? need : cap;
 }
-/* more than four pairs per CU: the gated kernel's job (cap: what that kernel can hold; 0 when there is none) */
-constexpr __host__ __device__ __forceinline__ bool pair_gated(uint32_t items, uint32_t n_cu, uint32_t cap) {
-    return cap > 4u && pair_quota(items, n_cu, cap) > 4u;
-}
-/* The host launches the gated twin only for batches of more than 4 x CUs wave slots (alacgpu.hip: launch): whatever the
- * cost table above says, it must never hand a batch that fits four rounds of the ungated kernel to the twin, or that batch
- * stays undecoded (round 3 had such a bug once, with another guess). Checked at compile time over every item count. */
-constexpr bool pair_never_gated_within_four(uint32_t n_cu) {
-    for (uint32_t cap = 5u; cap <= 8u; ++cap)
+/* The host launches the gated twin and the "fit 5" shape only for batches whose upper bound of wave slots exceeds 4 x CUs
+ * (alacgpu.hip: launch): whatever is decided above, it must never hand a batch of up to 4 x CUs slots to a launch that is
+ * not made for it, or that batch stays undecoded (round 3 had such a bug once, with another guess). Checked at compile time. */
+constexpr bool mode_is_fit4_within_four(uint32_t n_cu) {
+    for (uint32_t cap = 0u; cap <= 8u; ++cap)
         for (uint32_t items = 0u; items <= 4u * n_cu; ++items)
-            if (pair_gated(items, n_cu, cap)) return false;
+            if (decode_mode(items, n_cu, cap, 0u) != kModeFit4) return false;
     return true;
 }
-static_assert(pair_never_gated_within_four(1u) && pair_never_gated_within_four(7u) && pair_never_gated_within_four(64u) &&
-                  pair_never_gated_within_four(256u) && pair_never_gated_within_four(304u),
-              "pair_quota's table would leave batches of up to 4 x CUs wave slots to a kernel that is not launched for them");
+static_assert(mode_is_fit4_within_four(1u) && mode_is_fit4_within_four(7u) && mode_is_fit4_within_four(64u) &&
+                  mode_is_fit4_within_four(256u) && mode_is_fit4_within_four(304u),
+              "decode_mode would leave batches of up to 4 x CUs wave slots to a launch that is not made for them");
+constexpr uint32_t kQuadLdsFit4 = 34816u; /* static + dynamic LDS of a "fit 4" launch: 4 x 34 KB <= 160 KB < 5 x 34 KB */
 
 /* arguments of the pair kernels (k_decode_body.inc), passed as one struct */
 struct PairArgs {
@@ -549,6 +589,8 @@ struct PairArgs {
     uint32_t n_cu; /* compute units of the device */
     uint32_t cap;  /* pairs one of them holds */
     uint32_t lanes_min; /* four-wave workgroups (k_dec16q.hip): keys whose longer predictor has at least this many taps get two predictor waves */
+    uint32_t fit;       /* four-wave workgroups: how many of them a CU holds with THIS launch's LDS footprint (kModeFit4 / kModeFit5) */
+    uint32_t fit_force; /* experiments (ALACGPU_FIT): 4 / 5 for every batch; 0: decode_mode decides */
 };
 #define ALAC_DECLARE_DECODE(NAME) __global__ void NAME(PairArgs);
 /* the wave pair over the regular packets, one kernel per class (sample width x channel width) */

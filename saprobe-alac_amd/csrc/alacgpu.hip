@@ -221,6 +221,8 @@ struct alacgpu_decoder {
     char ahead_err[512];
     size_t last_n;                                           /* the last device decode: packets, packets per wave slot, PairArgs::cap */
     uint32_t last_ppw, last_cap;
+    uint32_t fit_force;                                      /* PairArgs::fit_force (ALACGPU_FIT) */
+    uint32_t order_exp;                                      /* ALACGPU_FIRST: 4 / 5 / 6, the launch of the narrow slots that goes first (experiments) */
 };
 
 namespace {
@@ -245,6 +247,21 @@ uint32_t pair_capacity(void (*kernel)(PairArgs)) {
     }
     cache.emplace_back((const void*)kernel, v);
     return (uint32_t)v;
+}
+
+/* static LDS of a four-wave kernel (what the "fit 4" launch pads up to kQuadLdsFit4: alac_gpu.h), asked once per kernel */
+uint32_t quad_static_lds(void (*kernel)(PairArgs)) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, uint32_t>> cache;
+    std::lock_guard<std::mutex> g(mu);
+    for (const auto& e : cache)
+        if (e.first == (const void*)kernel) return e.second;
+    hipFuncAttributes at;
+    uint32_t v = kQuadLdsFit4; /* unknown: no pad, and no second launch */
+    if (hipFuncGetAttributes(&at, (const void*)kernel) == hipSuccess) v = (uint32_t)at.sharedSizeBytes;
+    else (void)hipGetLastError();
+    cache.emplace_back((const void*)kernel, v);
+    return v;
 }
 
 /* Numbers the device's compute units for the pair kernels (k_decode_body.inc): XCD by XCD, so that CU number c is on
@@ -407,35 +424,57 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
          * kernel can hold (0: it has none); which of the twins works is decided on the device. */
         PairArgs a{c, d_blob, (uint64_t)blob_bytes, d_offsets, sz, (const uint32_t*)dec->perm.p, plan, d_out, (uint64_t)out_stride,
                    d_frames, d_status, (int32_t*)dec->scratch_u.p, (const uint32_t*)dec->cu_number.p,
-                   (uint32_t*)((uint8_t*)plan + plan_claims_offset()), ppw, dec->n_cu, 0u, dec->lanes_min};
+                   (uint32_t*)((uint8_t*)plan + plan_claims_offset()), ppw, dec->n_cu, 0u, dec->lanes_min, 4u, dec->fit_force};
         const uint32_t slots = (uint32_t)max_waves(dec, n, ppw);
-        auto pairs = [&](auto kernel, uint32_t roles = 2u) { hipLaunchKernelGGL(kernel, dim3(slots), dim3(roles * kWave), 0, dec->stream, a); };
-        /* One kernel per class of regular packets, each launched over all the wave slots; a kernel leaves the slots of the
-         * other classes alone, and whether a batch is the gated twin's (16-bit, slot counts between the multiples of
-         * 4 x CUs) or the four-wave kernel's is decided on the device from the plan's count of NARROW REGULAR slots
-         * (k_decode_body.inc: pair_gated): the host only knows an upper bound of all slots. The four-wave kernel is always
-         * launched; the gated twin whenever the upper bound exceeds 4 x CUs slots — below that no count of narrow slots can
-         * make pair_gated() true (k_decode_body.inc: the static_assert on pair_never_gated_within_four), so nothing the
-         * device relies on is skipped. (Round 3, found by tools/gpu_fuzz.py: a host-side guess of another kind once did
-         * skip a launch the device then relied on.) */
-        switch (dec->cfg.bit_depth) {
-            case 16:
-                a.cap = pair_capacity(alac_decode_16g);
-                dec->last_cap = a.cap;
-                pairs(alac_decode_16q, 4u);
-                /* as many workgroups as the device holds at once: they share the slots out among themselves */
-                if ((size_t)slots > (size_t)4 * dec->n_cu && a.cap > 4u)
-                    hipLaunchKernelGGL(alac_decode_16g, dim3(std::min<uint32_t>(a.cap * dec->n_cu, slots)), dim3(2 * kWave), 0,
-                                       dec->stream, a);
-                break;
-            case 32:
-                pairs(alac_decode_32q, 4u);
-                pairs(alac_decode_w32); /* chanBits > 23 only exists at 24 and 32 bits (without their usual shift bytes) */
-                break;
-            default: /* 20 and 24 */
-                pairs(alac_decode_24q, 4u);
-                if (dec->cfg.bit_depth == 24) pairs(alac_decode_w24);
+        auto pairs = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(slots), dim3(2 * kWave), 0, dec->stream, a); };
+        /* The narrow regular wave slots go to ONE of up to three launches, and which one is decided on the device from the
+         * plan's count of them (alac_gpu.h: decode_mode; the host only knows an upper bound of ALL slots): the four-wave
+         * kernel padded with dynamic LDS to 34 KB per workgroup ("fit 4": four per CU), the same kernel without the pad
+         * ("fit 5"), and for 16-bit streams the gated twin of wave pairs. "Fit 4" is always launched; the other two whenever
+         * the upper bound exceeds 4 x CUs slots — below that decode_mode() is "fit 4" whatever the device counts (the
+         * static_assert beside it), so nothing the device relies on is skipped. (Round 3, found by tools/gpu_fuzz.py: a
+         * host-side guess of another kind once did skip a launch the device then relied on.) The launches that are not the
+         * batch's exit at once — but an empty grid right IN FRONT of the one that works costs it up to 13 % (16-bit 98 304
+         * packets 3.15 -> 3.66 ms with the empty "fit 5" grid in front of the gated twin; behind it: nothing;
+         * profiles/r04_final/launch_order.txt), so the launch the host expects to work — decode_mode() of the batch as if
+         * every packet were a narrow regular one — goes first. A wrong guess costs speed, never correctness. */
+        const uint32_t n_cu = dec->n_cu;
+        const bool beyond4 = (size_t)slots > (size_t)4 * n_cu || dec->fit_force == kModeFit5;
+        auto quad = [&](auto kernel, uint32_t fit) {
+            const uint32_t stat = quad_static_lds(kernel);
+            const bool fits5 = (size_t)((stat + 1279u) / 1280u) * 1280u * 5u <= 163840u; /* 1280-byte granules of 160 KB */
+            if (fit == kModeFit5 && !(beyond4 && fits5)) return;
+            PairArgs q = a;
+            q.fit = fit;
+            hipLaunchKernelGGL(kernel, dim3(slots), dim3(4 * kWave), (fit == kModeFit4 && stat < kQuadLdsFit4) ? kQuadLdsFit4 - stat : 0u,
+                               dec->stream, q);
+        };
+        const bool has_twin = dec->cfg.bit_depth == 16;
+        if (has_twin) {
+            a.cap = pair_capacity(alac_decode_16g);
+            dec->last_cap = a.cap;
         }
+        auto narrow = [&](uint32_t mode) {
+            if (mode == kModeGated) {
+                /* as many workgroups as the device holds at once: they share the slots out among themselves */
+                if (has_twin && beyond4 && a.cap > 4u)
+                    hipLaunchKernelGGL(alac_decode_16g, dim3(std::min<uint32_t>(a.cap * n_cu, slots)), dim3(2 * kWave), 0, dec->stream, a);
+                return;
+            }
+            switch (dec->cfg.bit_depth) {
+                case 16: quad(alac_decode_16q, mode); break;
+                case 32: quad(alac_decode_32q, mode); break;
+                default: quad(alac_decode_24q, mode); /* 20 and 24 */
+            }
+        };
+        uint32_t guess = decode_mode((uint32_t)((n + ppw - 1) / ppw), n_cu, a.cap, dec->fit_force);
+        if (dec->order_exp) guess = dec->order_exp; /* experiments (ALACGPU_FIRST): which launch goes first */
+        narrow(guess);
+        for (uint32_t mode : {kModeFit4, kModeFit5, kModeGated})
+            if (mode != guess) narrow(mode);
+        /* the wide keys (chanBits > 23: 24- and 32-bit streams without their usual shift bytes): wave pairs */
+        if (dec->cfg.bit_depth == 32) pairs(alac_decode_w32);
+        else if (dec->cfg.bit_depth == 24) pairs(alac_decode_w24);
     }
     if (forked) scan();
     HIP_TRY(hipGetLastError());
@@ -586,6 +625,10 @@ void configure(alacgpu_decoder* d, const alacgpu_config* cfg, int bps) {
         if (v == 64 || v == 128 || v == 256) d->il_threads = (uint32_t)v;
     }
     d->lanes_min = 4;
+    d->fit_force = 0;
+    if (const char* e = getenv("ALACGPU_FIT")) d->fit_force = (uint32_t)atoi(e); /* experiments: 4 / 5 workgroups per CU for every batch */
+    d->order_exp = 0;
+    if (const char* e = getenv("ALACGPU_FIRST")) d->order_exp = (uint32_t)atoi(e);
     if (const char* e = getenv("ALACGPU_LANES_MIN")) d->lanes_min = (uint32_t)std::max(1, atoi(e)); /* experiments; 17: never */
     d->side = 2;
     if (const char* e = getenv("ALACGPU_SIDE")) d->side = atoi(e); /* experiments, tests */
@@ -1108,8 +1151,10 @@ int alacgpu_last_dispatch(alacgpu_decoder* d, alacgpu_dispatch* out) {
     const char* narrow = "";
     if (lean && out->narrow_slots) {
         const char* q = d->cfg.bit_depth == 16 ? "alac_decode_16q" : d->cfg.bit_depth == 32 ? "alac_decode_32q" : "alac_decode_24q";
-        narrow = (d->cfg.bit_depth == 16 && pair_gated(out->narrow_slots, d->n_cu, d->last_cap)) ? "alac_decode_16g" : q;
-        out->gated = narrow[14] == 'g' ? 1u : 0u;
+        const uint32_t mode = decode_mode(out->narrow_slots, d->n_cu, d->last_cap, d->fit_force);
+        narrow = mode == kModeGated ? "alac_decode_16g" : q;
+        out->gated = mode == kModeGated ? 1u : 0u;
+        out->workgroups_per_cu = mode == kModeGated ? pair_quota(out->narrow_slots, d->n_cu, d->last_cap) : mode;
         /* predictor waves on several lanes per packet (k_decode_body.inc: lanes_ok) */
         if (!out->gated && out->narrow_slots <= d->n_cu + d->n_cu / 8u && d->lanes_min <= 16u) out->lanes_per_packet = d->last_ppw <= 32u ? 4u : 2u;
     }

@@ -20,6 +20,9 @@
  * 65 536 packets 3.32 -> 2.57, 98 304 4.94 -> 4.45, 131 072 5.70 -> 4.74; 32-bit stereo 4.85 -> 4.26, 98 304 8.51 -> 7.66;
  * 24-bit mono 2.23 -> 1.91; A/B in one process. The two-wave kernels of the narrow keys are gone.)
  */
+/* 26 KB of static LDS: five of these workgroups fit a CU ("fit 5"); launched with a dynamic-LDS pad for four (alac_gpu.h: decode_mode) */
+#define ALAC_LDS_ROWS 32
+#define ALAC_LDS_FLUSH 32
 #include "alac_gpu.h"
 
 #define ALAC_DECODE_KERNEL alac_decode_16q

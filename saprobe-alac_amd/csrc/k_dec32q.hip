@@ -3,6 +3,9 @@
  * 32-bit streams with their usual shift bytes, chanBits <= 23: every batch size (these widths have no gated twin: their writers
  * need more registers than three waves per SIMD leave).
  */
+/* 26 KB of static LDS: five of these workgroups fit a CU ("fit 5"); launched with a dynamic-LDS pad for four (alac_gpu.h: decode_mode) */
+#define ALAC_LDS_ROWS 32
+#define ALAC_LDS_FLUSH 32
 #include "alac_gpu.h"
 
 #define ALAC_DECODE_KERNEL alac_decode_32q

@@ -58,7 +58,7 @@ static __device__ __forceinline__ void scan_slot(uint32_t b, const alac::DevCfg&
     wv.ppw = ppw;
     wv.my_out = nullptr;
     wv.lane = lane;
-    wv.wcnt = wv.flushed = 0;
+    wv.wcnt = wv.flushed = wv.wpos = wv.fpos = 0;
 
     /* lanes without a packet read nothing (size 0) */
     const uint64_t off = live ? offsets[pkt] : 0ull;
@@ -126,7 +126,7 @@ static __device__ __forceinline__ void legacy_slot(uint32_t b, const alac::DevCf
     wv.ppw = ppw;
     wv.my_out = nullptr;
     wv.lane = lane;
-    wv.wcnt = wv.flushed = 0;
+    wv.wcnt = wv.flushed = wv.wpos = wv.fpos = 0;
     /* lanes without a packet read nothing (size 0) */
     const uint64_t off = live ? offsets[pkt] : 0ull;
     const uint8_t* p = blob + off;

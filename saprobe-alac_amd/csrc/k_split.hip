@@ -32,7 +32,7 @@ alac_chan_predict(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t b
     wv.ppw = ppw;
     wv.my_out = nullptr;
     wv.lane = lane;
-    wv.wcnt = wv.flushed = 0;
+    wv.wcnt = wv.flushed = wv.wpos = wv.fpos = 0;
     wv.it = 0;
     wv.chunk0 = 0;
 

@@ -536,6 +536,72 @@ def test_batches_between_the_rounds_take_the_gated_pairs(pkg, synth, oracle, hel
         assert (place[tags != 0, 2] != place[tags != 0, 1]).all()  # start and end clocks recorded
 
 
+@pytest.mark.parametrize("depth,ch,n,fl,profile,force", [(24, 2, 70000, 48, 0, None), (32, 2, 70000, 40, 0, None), (20, 1, 75000, 37, 3, None),
+                                                         (24, 2, 140000, 35, 2, None), (16, 2, 70000, 64, 0, "5"), (16, 1, 20000, 100, 3, "5"),
+                                                         (24, 2, 9000, 130, 3, "5"), (16, 2, 70000, 64, 0, "4")])
+def test_five_four_wave_workgroups_per_cu(pkg, synth, oracle, helpers, gpu_decoder_factory, monkeypatch, depth, ch, n, fl, profile, force):
+    """Round 4: the four-wave kernels launched without their dynamic-LDS pad ("fit 5": five workgroups share a CU, alac_gpu.h:
+    decode_mode) — batches whose narrow wave slots number 4..5 x CUs or more than 7 x CUs, the widths without a gated twin, the
+    48-dword stager rows of the 3-byte writer, partial frames, and the shape forced on (ALACGPU_FIT) for batches of other sizes
+    and for the 16-bit kernel, whose batches of that size the gated twin takes otherwise. PCM, frame counts and status words are
+    the oracle's (golomb.go:148, predictor.go:45, matrix.go:30); the dispatch read back from the device names the shape."""
+    import torch
+    if force is None:
+        monkeypatch.delenv("ALACGPU_FIT", raising=False)
+    else:
+        monkeypatch.setenv("ALACGPU_FIT", force)
+    cfg = oracle.make_config(fl, depth, ch)
+    b = synth.gen_batch(cfg, n, profile=profile, base_seed=depth * 1000 + fl, threads=16)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    with gpu_decoder_factory(cfg) as dec:
+        got = _gpu_decode(dec, b.blob, b.offsets, b.sizes)
+        disp = dec.last_dispatch()
+    ref = oracle.decode_batch(cfg, b.blob, b.offsets, b.sizes, threads=16)
+    helpers.assert_same_decode(cfg, ref, got, bpf, "n=%d fit %s" % (n, force))
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    q = disp["narrow_slots"] / n_cu
+    if force is not None:
+        assert disp["workgroups_per_cu"] == int(force) and not disp["gated"]
+    else:  # widths without a gated twin (alac_gpu.h: decode_mode)
+        want = 4 if q <= 4 else 5 if q <= 5 else 4 if q <= 7 else 5
+        assert disp["workgroups_per_cu"] == want and not disp["gated"], (q, disp)
+        if n_cu == 256 and profile != 3:  # the sizes above are chosen for an MI355X (STRESS batches hold irregular packets too)
+            assert want == 5, q
+
+
+def test_24bit_batch_just_above_four_rounds_at_full_frame_length(pkg, synth, oracle, gpu_decoder_factory):
+    """66 000 x 24-bit stereo 4096-frame packets — eight wave slots more than 4 x CUs, which used to
+    cost a whole second round (3.88 ms against 2.62 for 65 536) and now run as a fifth workgroup on some CUs. Checked by
+    decode(encode(pcm)) == pcm (tests/conformance_test.go:282-291), frame counts and status words; the oracle decodes a slice."""
+    import torch
+    n, ch = 66000, 2
+    cfg = oracle.make_config(4096, 24, ch)
+    b = synth.gen_batch(cfg, n, threads=16)
+    dev = torch.device("cuda:0")
+    stride = 4096 * ch * 3
+    d_blob = torch.from_numpy(b.blob).to(dev)
+    d_off = torch.from_numpy(b.offsets.astype(np.int64)).to(dev)
+    d_sz = torch.from_numpy(b.sizes.astype(np.int32)).to(dev)
+    d_out = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    d_fr = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with gpu_decoder_factory(cfg) as dec:
+        dec.decode_batch_device(d_blob.data_ptr(), d_blob.numel(), d_off.data_ptr(), d_sz.data_ptr(), n, d_out.data_ptr(),
+                                stride, d_fr.data_ptr(), d_st.data_ptr(), sync=True)
+        disp = dec.last_dispatch()
+    assert int(d_st.abs().sum()) == 0
+    assert np.array_equal(d_fr.cpu().numpy().astype(np.uint32), b.frames)
+    for lo in range(0, n, 4096):
+        exp = torch.from_numpy(b.pcm[lo:lo + 4096]).to(dev)
+        assert torch.equal(d_out[lo:lo + 4096], exp), lo
+        del exp
+    ref = oracle.decode_batch(cfg, b.blob, b.offsets[-128:], b.sizes[-128:], threads=8)
+    assert np.array_equal(ref[0], d_out[-128:].cpu().numpy())
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert disp["workgroups_per_cu"] == 5 and disp["narrow_kernel"] == "alac_decode_24q", disp
+
+
 def test_gated_pairs_with_corrupt_packets_and_two_handles_at_once(pkg, synth, oracle, helpers, gpu_decoder_factory):
     """The gated kernel under the conditions the small-batch tests never reach it in: a batch of 84 000 packets of which
     every tenth is damaged (the status words of DynDecomp's error paths, golomb.go:157-163,196-199,239-245, must be the
