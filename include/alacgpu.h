@@ -116,15 +116,17 @@ typedef struct alacgpu_decoder alacgpu_decoder;
 int alacgpu_create(const alacgpu_config* cfg, int device, alacgpu_decoder** out);
 /* A destroyed handle's streams, events and small buffers are kept for the next alacgpu_create on the same device: a file
  * decoder makes and drops a handle per file (decode.go:50-80), and building one from nothing costs several times the
- * decode of a short file. Kept per handle: at most 128 MB of device memory and 64 MB of pinned host memory (the largest
- * buffers are dropped first); four handles per device. alacgpu_trim() frees what is kept. */
+ * decode of a short file. Kept per handle: at most 2 GB of device memory (a handle's workspace is mostly the U hand-off
+ * tiles, (frame_length + 1) x 256 bytes per wave slot: 1 GB for the 1 024-packet windows of a 24-bit file decoder, and
+ * letting go of it means hipFree, which waits for the whole device) and 64 MB of pinned host memory (the largest buffers are
+ * dropped first); four handles per device, so at most 8 GB of the device's 288 GB. alacgpu_trim() frees what is kept. */
 void alacgpu_destroy(alacgpu_decoder* dec);
 void alacgpu_trim(void);
 
 /* Pinned (page-locked) host memory for the buffers a caller hands to alacgpu_decode_batch: what that entry finds in pinned
  * memory it transfers in place instead of through its own staging copies (a third of the time of a file decode goes into
- * those). NULL when the runtime refuses. Freed buffers of up to 64 MB are kept for the next alacgpu_host_alloc (at most
- * four; alacgpu_trim() frees them). */
+ * those). NULL when the runtime refuses. Freed buffers of up to 64 MB are kept for the next alacgpu_host_alloc (the eight
+ * newest, 192 MB in all; alacgpu_trim() frees them). */
 void* alacgpu_host_alloc(size_t bytes);
 void alacgpu_host_free(void* p);
 

@@ -538,9 +538,10 @@ __global__ void alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, 
  * the kernel is bound by). Five pay (profiles/r04_final/fit_sweep.txt; q = slots per CU):
  *   4 < q <= 5   a round of five instead of four and a nearly empty one (24-bit 81 920 packets 4.16 -> 3.35 ms, 32-bit
  *                7.11 -> 4.78; 16-bit 3.18 -> 2.95, where the gated pairs of k_dec16g.hip are as fast or faster and keep the batch);
- *   q > 7        the dispatcher refills a CU workgroup by workgroup, and with five resident the tail of one "round" overlaps
+ *   q > 7.5      the dispatcher refills a CU workgroup by workgroup, and with five resident the tail of one "round" overlaps
  *                the start of the next (16-bit 131 072 packets 4.55 -> 4.24 ms, 163 840 5.37 -> 5.21; 24-bit 131 072 6.42 -> 5.25).
- * Between (5 < q <= 7) four per CU win (16-bit 114 688 packets 3.67 against 3.89 ms, 24-bit 98 304 4.52 against 4.64). */
+ * Between (5 < q <= 7.5) four per CU win (16-bit 114 688 packets 3.67 against 3.89 ms, 24-bit 98 304 4.52 against 4.64,
+ * 122 880 4.58 against 4.71). */
 constexpr uint32_t kModeFit4 = 4u, kModeFit5 = 5u, kModeGated = 6u;
 /* cap: pairs per CU the width's gated twin holds (0: it has none); force (ALACGPU_FIT): 4 / 5 for every batch, no gated twin */
 constexpr __host__ __device__ __forceinline__ uint32_t decode_mode(uint32_t items, uint32_t n_cu, uint32_t cap, uint32_t force) {
@@ -548,7 +549,7 @@ constexpr __host__ __device__ __forceinline__ uint32_t decode_mode(uint32_t item
     if (items <= 4u * n_cu) return kModeFit4;
     if (items <= 5u * n_cu) return cap >= 5u ? kModeGated : kModeFit5;
     if (items <= 6u * n_cu && cap >= 6u) return kModeGated;
-    return items <= 7u * n_cu ? kModeFit4 : kModeFit5;
+    return 2u * items <= 15u * n_cu ? kModeFit4 : kModeFit5;
 }
 /* pairs per CU the gated twin admits (k_decode_body.inc: the gate): as few as hold the batch at once */
 constexpr __host__ __device__ __forceinline__ uint32_t pair_quota(uint32_t items, uint32_t n_cu, uint32_t cap) {

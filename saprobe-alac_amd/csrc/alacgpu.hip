@@ -554,12 +554,16 @@ std::vector<alacgpu_decoder*> g_pool;
 std::vector<std::pair<void*, size_t>> g_host_pool;  /* alacgpu_host_free: pinned buffers waiting for the next alacgpu_host_alloc */
 std::vector<std::pair<void*, size_t>> g_host_sizes; /* live alacgpu_host_alloc buffers and their sizes */
 constexpr size_t kPoolPerDevice = 4;
-/* what a pooled handle keeps: device buffers of at most 128 MB in all, pinned host staging of at most 64 MB in all (the
- * largest go first) — enough for the windows of a file decoder (stream.py: 4 096 packets), not the workspace of a
- * 65 536-packet batch. Four handles per device: at most 0.5 GB of device memory and 0.25 GB of pinned memory per device
- * stay allocated behind alacgpu_destroy() until alacgpu_trim(). */
-constexpr size_t kPoolKeepDevice = (size_t)128 << 20;
+/* what a pooled handle keeps: device buffers of at most 2 GB in all, pinned host staging of at most 64 MB in all (the
+ * largest go first). Device memory is what an MI355X has plenty of (288 GB), and what a file decoder's handles need most of:
+ * U hand-off tiles of 1 MB per wave slot, 912 slots for a 1 024-packet window of a 24-bit stream (max_waves) — 1 GB that
+ * round 4's first file benchmark allocated and freed per file, with a device-wide hipFree in the middle of the stream.
+ * Four handles per device: at most 8 GB of device memory and 0.25 GB of pinned memory per device stay allocated behind
+ * alacgpu_destroy() until alacgpu_trim(). */
+constexpr size_t kPoolKeepDevice = (size_t)2048 << 20;
 constexpr size_t kPoolKeepPinned = (size_t)64 << 20;
+/* alacgpu_host_free keeps blocks of up to 64 MB, the eight newest, 192 MB in all (three windows of a file decoder, a few sizes) */
+constexpr size_t kHostPoolBlock = (size_t)64 << 20, kHostPoolBytes = (size_t)192 << 20, kHostPoolCount = 8;
 template <class Buf>
 void keep_at_most(std::vector<Buf*> bufs, size_t limit) {
     for (;;) {
@@ -766,9 +770,9 @@ void alacgpu_trim(void) {
 }
 
 /* Pinned host memory for a caller's PCM (or packet) buffers: what alacgpu_decode_batch finds in pinned memory it
- * transfers in place, without the copy through its staging. Freed buffers of up to 64 MB are kept (at most four, the
- * smallest that fits is handed out again): a file decoder asks for the same sizes file after file, and hipHostMalloc
- * costs milliseconds. */
+ * transfers in place, without the copy through its staging. Freed buffers of up to 64 MB are kept (the eight newest, 192 MB
+ * in all; the smallest that fits is handed out again): a file decoder asks for the same sizes file after file, and
+ * hipHostMalloc / hipHostFree cost milliseconds each and stall the device. */
 void* alacgpu_host_alloc(size_t bytes) {
     if (bytes == 0) bytes = 1;
     {
@@ -799,6 +803,7 @@ void* alacgpu_host_alloc(size_t bytes) {
 void alacgpu_host_free(void* p) {
     if (!p) return;
     size_t bytes = 0;
+    std::vector<void*> evict;
     {
         std::lock_guard<std::mutex> g(g_pool_mu);
         for (size_t i = 0; i < g_host_sizes.size(); i++)
@@ -807,12 +812,22 @@ void alacgpu_host_free(void* p) {
                 g_host_sizes.erase(g_host_sizes.begin() + (long)i);
                 break;
             }
-        if (bytes && bytes <= ((size_t)64 << 20) && g_host_pool.size() < 4) {
+        if (bytes && bytes <= kHostPoolBlock) {
+            /* newest last; what no longer fits goes oldest first (round 4: a pool of four blocks, first come first kept,
+             * filled up with the small windows of short files and then made every long file allocate and free its own) */
             g_host_pool.emplace_back(p, bytes);
-            return;
+            p = nullptr;
+            size_t total = 0;
+            for (const auto& h : g_host_pool) total += h.second;
+            while (g_host_pool.size() > kHostPoolCount || total > kHostPoolBytes) {
+                evict.push_back(g_host_pool.front().first);
+                total -= g_host_pool.front().second;
+                g_host_pool.erase(g_host_pool.begin());
+            }
         }
     }
-    (void)hipHostFree(p);
+    for (void* q : evict) (void)hipHostFree(q);
+    if (p) (void)hipHostFree(p);
 }
 
 int alacgpu_get_format(const alacgpu_decoder* d, alacgpu_format* fmt) {

@@ -84,7 +84,7 @@ public:
     }
 
     alacgpu_decoder* handle() const { return h_.get(); }
-    // alacgpu_trim(): destroyed decoders leave streams, events and small buffers (<= 128 MB of device memory and
+    // alacgpu_trim(): destroyed decoders leave streams, events and small buffers (<= 2 GB of device memory and
     // 64 MB of pinned memory each, four per device) in a per-process pool for the next one; this frees them
     static void Trim() { alacgpu_trim(); }
 

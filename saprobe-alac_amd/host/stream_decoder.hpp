@@ -4,10 +4,14 @@
 // Same surface (NewDecoder, Format, Duration, Position, Seek, Read) and the same observable behaviour: PCM bytes
 // in packet order, packet-aligned seeks, the error of packet k when the reader reaches packet k and again on every
 // later Read. The PCM is made differently: a window of packets goes through ONE batch decode on the GPU
-// (alacgpu_decode_batch) and Read / Seek are served from the decoded window — and while the caller drains window k, a
-// worker thread has window k + 1 decoded into a second buffer (round 4: a 300-second file spent as long in Read's copies
-// as in the decode; now the two overlap). Window PCM lives in pinned memory (alacgpu_host_alloc): the device writes it
-// there directly. Header-only; link with -lalacgpu -pthread.
+// (alacgpu_decode_batch) and Read / Seek are served from the decoded window — and while the caller drains window k, worker
+// threads have windows k + 1 and k + 2 decoded into buffers of their own, on TWO handles (round 4: a 300-second file spent
+// as long in Read's copies as in the decode; a window's decode is a chain of staging copy, upload, a kernel that takes its
+// 1.2 ms however few packets it holds, and download — two chains in flight fill each other's gaps, and the reader's copies
+// run beside both). Every window has the same size, and both handles reserve their workspace for it when the file is
+// opened: a buffer that grows in the middle of a stream is freed first, and hipFree waits for the whole device (a first
+// window of a quarter of the size cost the windows behind it 4-5 ms each that way). Window PCM lives in pinned memory
+// (alacgpu_host_alloc): the device writes it there directly. Header-only; link with -lalacgpu -pthread.
 #pragma once
 
 #include <algorithm>
@@ -16,6 +20,15 @@
 
 #include "mp4_demux.hpp"
 #include "packet_decoder.hpp"
+
+#ifdef ALAC_STREAM_TRACE  // tools/r4_cppfile.py: where a file decode's time goes (stderr, microseconds since the first event)
+#include <chrono>
+#include <cstdio>
+namespace alac { inline double TraceUs() { static const auto t0 = std::chrono::steady_clock::now(); return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } }
+#define ALAC_TRACE(...) (std::fprintf(stderr, "%10.1f ", alac::TraceUs()), std::fprintf(stderr, __VA_ARGS__), std::fputc('\n', stderr))
+#else
+#define ALAC_TRACE(...) ((void)0)
+#endif
 
 namespace alac {
 
@@ -51,8 +64,10 @@ inline PacketConfig ParseMagicCookie(const uint8_t* d, size_t n) {
 class Decoder {
 public:
     // The file must stay mapped / alive for the lifetime of the decoder. window = packets per batch decode (the read-ahead
-    // runs one window ahead of the reader; 1024 packets are 16 MB of CD audio).
-    Decoder(const uint8_t* file, size_t len, int device = 0, size_t window = 1024) : file_(file), len_(len), window_(std::max<size_t>(1, window)) {
+    // runs two windows ahead of the reader); 0: as many as make 48 MB of PCM (3 072 packets of CD audio, 2 048 of 96 kHz /
+    // 24-bit stereo: a 300-second file of the latter takes 16.5 ms with windows of 1 024 packets and 11.6 ms with 2 048; three
+    // such windows still fit the library's pool of pinned blocks, larger ones are allocated and freed per file: 86 ms).
+    Decoder(const uint8_t* file, size_t len, int device = 0, size_t window = 0) : file_(file), len_(len), window_(window) {
         try {
             track_ = mp4::FindALACTrack(file, len);
         } catch (const mp4::Error& e) {
@@ -63,19 +78,22 @@ public:
         } catch (const ErrConfig& e) {
             throw ErrConfig(std::string("parsing ALAC config: ") + e.what());  // decode.go:57-59
         }
-        dec_ = NewPacketDecoder(config_, device);
-        stride_ = alacgpu_frame_bytes(dec_->handle());
+        dec_[0] = NewPacketDecoder(config_, device);
+        dec_[1] = NewPacketDecoder(config_, device);  // destroyed handles are pooled by the library: two per file cost nothing
+        stride_ = alacgpu_frame_bytes(dec_[0]->handle());
+        if (window_ == 0) window_ = std::max<size_t>(64, ((size_t)48 << 20) / std::max<size_t>(1, stride_));
+        for (auto& d : dec_) (void)alacgpu_reserve(d->handle(), std::min(window_, Packets()));
         const unsigned bps = config_.bit_depth == 16 ? 2 : config_.bit_depth == 32 ? 4 : 3;
         bpf_ = (size_t)config_.num_channels * bps;
     }
     ~Decoder() {
-        Settle();
+        Drop();
         for (Window& w : win_) w.Free();
     }
     Decoder(const Decoder&) = delete;
     Decoder& operator=(const Decoder&) = delete;
 
-    PCMFormat Format() const { return dec_->Format(); }
+    PCMFormat Format() const { return dec_[0]->Format(); }
     const PacketConfig& Config() const { return config_; }
     size_t Packets() const { return track_.sizes.size(); }
     // nanoseconds, as time.Duration (decode.go:82-98)
@@ -155,11 +173,12 @@ private:
         }
     };
 
-    // packets [first, first + window) into w: one batch decode (runs on the caller's thread or on the read-ahead worker:
-    // never both at once, the handle is not safe for concurrent use)
-    void DecodeWindow(Window& w, size_t first) {
-        size_t last = std::min(first + window_, Packets());
+    // packets [first, first + count) into w: one batch decode on handle `dec` (the caller's thread or a read-ahead worker;
+    // a handle is never used by two of them at once)
+    void DecodeWindow(Window& w, size_t first, size_t count, PacketDecoder& dec) {
+        size_t last = std::min(first + count, Packets());
         w.lost = SIZE_MAX;
+        w.w0 = w.w1 = first;
         for (size_t k = first; k < last; ++k)
             if (track_.offsets[k] > len_ || track_.sizes[k] > len_ - track_.offsets[k]) {
                 w.lost = k;
@@ -185,40 +204,80 @@ private:
                 blob = &none;
                 blob_bytes = 0;
             }
+            ALAC_TRACE("window %zu +%zu: reserve", first, n);
             w.Reserve(n, stride_);
-            dec_->DecodePackets(blob, blob_bytes, w.starts.data(), n, w.out, stride_, w.frames, w.status);
+            ALAC_TRACE("window %zu +%zu: decode begins (pinned %d)", first, n, (int)w.pinned);
+            dec.DecodePackets(blob, blob_bytes, w.starts.data(), n, w.out, stride_, w.frames, w.status);
+            ALAC_TRACE("window %zu +%zu: decode done", first, n);
         }
-        w.w0 = first;
         w.w1 = last;
     }
-    // waits for the read-ahead (if any); its window becomes valid or its error is dropped (the reader will meet it again)
-    void Settle() {
-        if (!ahead_.valid()) return;
+    // the read-aheads in flight, oldest first: window `slot` is being filled with the packets from `first` on
+    struct Ahead {
+        std::future<void> done;
+        size_t first = 0, count = 0;
+        unsigned slot = 0;
+    };
+    static constexpr unsigned kDepth = 2;
+    // waits for the oldest read-ahead; true: its window is valid (false: its error is dropped, the reader will meet it again)
+    bool Settle() {
+        bool ok = true;
         try {
-            ahead_.get();
-            ahead_ok_ = true;
+            ahead_[0].done.get();
         } catch (...) {
-            ahead_ok_ = false;
+            ok = false;
+        }
+        for (unsigned i = 1; i < n_ahead_; ++i) ahead_[i - 1] = std::move(ahead_[i]);
+        --n_ahead_;
+        return ok;
+    }
+    void Drop() {
+        while (n_ahead_) (void)Settle();
+    }
+    // keeps kDepth windows in flight behind the current one (consecutive windows take turns on the two handles, so the
+    // two in flight never share one)
+    void Schedule() {
+        const Window& c = win_[cur_];
+        if (c.lost != SIZE_MAX || c.w1 <= c.w0) return;  // the stream ends at the lost sample
+        while (n_ahead_ < kDepth) {
+            const size_t first = n_ahead_ ? ahead_[n_ahead_ - 1].first + ahead_[n_ahead_ - 1].count : c.w1;
+            if (first >= Packets()) return;
+            unsigned slot = 0;
+            for (;; ++slot) {
+                bool used = slot == cur_;
+                for (unsigned i = 0; i < n_ahead_; ++i) used = used || ahead_[i].slot == slot;
+                if (!used) break;
+            }
+            Ahead& a = ahead_[n_ahead_++];
+            a.first = first;
+            a.count = std::min(window_, Packets() - first);
+            a.slot = slot;
+            Window* w = &win_[slot];
+            PacketDecoder* dec = dec_[seq_++ & 1u].get();
+            const size_t count = a.count;
+            a.done = std::async(std::launch::async, [this, w, first, count, dec] { DecodeWindow(*w, first, count, *dec); });
         }
     }
     void NextPacket() {
         const size_t k = idx_;
         if (!win_[cur_].Holds(k)) {
-            Settle();
-            Window& other = win_[cur_ ^ 1u];
-            if (ahead_ok_ && other.Holds(k)) {
-                cur_ ^= 1u;
-            } else {  // the first window, a seek, or a read-ahead that failed: decode here (and let its error out)
-                DecodeWindow(win_[cur_], k);
+            bool have = false;
+            if (n_ahead_ && ahead_[0].first == k) {  // the reader walked off the end of its window into the next one
+                const unsigned slot = ahead_[0].slot;
+                ALAC_TRACE("reader at %zu: waits", k);
+                const bool ok = Settle();
+                ALAC_TRACE("reader at %zu: has its window", k);
+                if (ok && win_[slot].Holds(k)) {
+                    cur_ = slot;
+                    have = true;
+                }
             }
-            ahead_ok_ = false;
-            // the window behind this one, while the caller drains this one
-            Window& c = win_[cur_];
-            if (c.lost == SIZE_MAX && c.w1 < Packets() && c.w1 > c.w0) {
-                Window* nxt = &win_[cur_ ^ 1u];
-                const size_t first = c.w1;
-                ahead_ = std::async(std::launch::async, [this, nxt, first] { DecodeWindow(*nxt, first); });
+            if (!have) {  // the first window, a seek, or a read-ahead that failed: decode here (and let its error out)
+                Drop();
+                seq_ = 1;
+                DecodeWindow(win_[cur_], k, window_, *dec_[0]);
             }
+            Schedule();
         }
         Window& w = win_[cur_];
         if (w.lost == k) throw ErrRead("reading sample " + std::to_string(k) + ": unexpected EOF");
@@ -234,19 +293,19 @@ private:
     size_t len_, window_;
     mp4::Track track_;
     PacketConfig config_{};
-    std::unique_ptr<PacketDecoder> dec_;
+    std::unique_ptr<PacketDecoder> dec_[2];
     size_t stride_ = 0, bpf_ = 0;
     size_t idx_ = 0;
     const uint8_t* buf_ = nullptr;
     size_t buf_off_ = 0, buf_len_ = 0;
     bool eof_ = false;
-    Window win_[2];
+    Window win_[kDepth + 1];
     unsigned cur_ = 0;
-    std::future<void> ahead_;  // the read-ahead of win_[cur_ ^ 1]
-    bool ahead_ok_ = false;
+    Ahead ahead_[kDepth];
+    unsigned n_ahead_ = 0, seq_ = 0;
 };
 
-inline std::unique_ptr<Decoder> NewDecoder(const uint8_t* file, size_t len, int device = 0, size_t window = 1024) {
+inline std::unique_ptr<Decoder> NewDecoder(const uint8_t* file, size_t len, int device = 0, size_t window = 0) {
     return std::make_unique<Decoder>(file, len, device, window);
 }
 

@@ -5,8 +5,11 @@ packet order, packet-aligned seeks, the error for packet k raised when the reade
 every later Read. What differs is how the PCM gets made: instead of one DecodePacket per packet the decoder reads
 ahead — a window of packets goes through ONE batch decode on the GPU (`alacgpu_decode_batch`: gather, H2D, the
 kernels, D2H) and Read / Seek are served from the decoded window. While the caller drains window k the library has
-window k + 1 decoded on a thread of its own (alacgpu_decode_batch_start / _wait: a Python thread would spend the time
-waiting for the interpreter lock the draining loop holds), as host/stream_decoder.hpp does.
+windows k + 1 and k + 2 decoded on threads of its own, on two handles (alacgpu_decode_batch_start / _wait: a Python thread
+would spend the time waiting for the interpreter lock the draining loop holds; a window's decode is a chain of staging copy,
+upload, a kernel that takes its 1.2 ms however few packets it holds, and download — two chains in flight fill each other's
+gaps), as host/stream_decoder.hpp does. Every window has the same size and both handles reserve their workspace for it
+up front: a buffer that grows in the middle of a stream is freed first, and hipFree waits for the whole device.
 """
 import os
 
@@ -34,9 +37,10 @@ def _as_buffer(source):
 
 
 class Decoder:
-    """Streams decoded PCM from an ALAC M4A/MP4 source (decode.go:32-45). `window` = packets per batch decode."""
+    """Streams decoded PCM from an ALAC M4A/MP4 source (decode.go:32-45). `window` = packets per batch decode; 0: as many
+    as make 48 MB of PCM (host/stream_decoder.hpp)."""
 
-    def __init__(self, source, device=0, window=1024):
+    def __init__(self, source, device=0, window=0):
         self._data = _as_buffer(source)
         self._view = memoryview(self._data).cast("B") if not isinstance(self._data, np.ndarray) else memoryview(self._data)
         try:
@@ -52,9 +56,12 @@ class Decoder:
             err.sentinel = e.sentinel
             raise err from None
         self._dec = NewPacketDecoder(self.config, device)
+        self._decs = (self._dec, NewPacketDecoder(self.config, device))  # destroyed handles are pooled by the library
+        for d in self._decs:
+            d.reserve(min(int(window) if int(window) > 0 else max(64, (48 << 20) // max(1, self._dec.frame_bytes)), max(1, len(track.sizes))))
         self._offsets, self._sizes = track.offsets, track.sizes
         self._bpf = self.config.NumChannels * bytes_per_sample(self.config.BitDepth)
-        self._window = max(1, int(window))
+        self._window = int(window) if int(window) > 0 else max(64, (48 << 20) // max(1, self._dec.frame_bytes))
         self._idx = 0                    # sampleIdx: next packet to hand out
         self._buf = b""                  # PCM of the packet being drained (decode.go:40-42)
         self._buf_off = 0
@@ -62,7 +69,8 @@ class Decoder:
         self._w0 = self._w1 = 0          # decoded window: packets [w0, w1)
         self._w_out = self._w_frames = self._w_status = None
         self._w_read_err = None          # (packet index, message): a sample that lies outside the file
-        self._ahead = None               # (thread, box): the window behind the current one, being decoded
+        self._aheads = []                # the windows behind the current one, being decoded: [w0, w1, planned end, read_err, token, decoder], oldest first
+        self._seq = 0                    # consecutive windows take turns on the two handles
 
     # ---- decode.go:79-124 -------------------------------------------------------------------------------
     def Format(self):
@@ -88,9 +96,9 @@ class Decoder:
         return (self._idx * fl * 1_000_000_000 // sr) / 1e9
 
     # ---- the read-ahead window -------------------------------------------------------------------------------
-    def _prepare(self, first):
-        """Packets [first, first + window): -> (w0, w1, blob, starts, read_err), nothing decoded yet."""
-        last = min(first + self._window, len(self._sizes))
+    def _prepare(self, first, count):
+        """Packets [first, first + count): -> (w0, w1, blob, starts, read_err), nothing decoded yet."""
+        last = min(first + count, len(self._sizes))
         offs = self._offsets[first:last].astype(np.int64)
         sizes = self._sizes[first:last].astype(np.int64)
         n_file = len(self._view)
@@ -115,9 +123,9 @@ class Decoder:
             blob = np.zeros(1, np.uint8)  # only empty packets: the entry still wants a readable pointer
         return first, last, blob, starts, read_err
 
-    def _decode(self, first):
+    def _decode(self, first, count):
         """-> (w0, w1, out, frames, status, read_err): one batch decode, here and now."""
-        w0, w1, blob, starts, read_err = self._prepare(first)
+        w0, w1, blob, starts, read_err = self._prepare(first, count)
         out = frames = status = None
         if w1 > w0:
             out, frames, status = self._dec.decode_batch(blob, starts)
@@ -127,26 +135,45 @@ class Decoder:
         self._w0, self._w1, self._w_out, self._w_frames, self._w_status, self._w_read_err = w
 
     def _settle(self):
-        """Waits for the read-ahead; -> its window, or None (none running, or it failed: the reader meets the error again)."""
-        if self._ahead is None:
-            return None
-        (w0, w1, read_err), token = self._ahead
-        self._ahead = None
+        """Waits for the oldest read-ahead; -> its window, or None (it failed: the reader meets the error again)."""
+        w0, w1, _, read_err, token, dec = self._aheads.pop(0)
         try:
-            out, frames, status = self._dec.decode_batch_wait(token)
+            out, frames, status = dec.decode_batch_wait(token)
         except AlacError:
             return None
         return w0, w1, out, frames, status, read_err
 
+    def _drop(self):
+        while self._aheads:
+            self._settle()
+
+    def _schedule(self):
+        """Keeps two windows in flight behind the current one."""
+        if self._w_read_err is not None or self._w1 <= self._w0:
+            return  # the stream ends at the lost sample
+        while len(self._aheads) < 2:
+            first = self._aheads[-1][2] if self._aheads else self._w1
+            if first >= len(self._sizes):
+                return
+            n0, n1, blob, starts, read_err = self._prepare(first, self._window)
+            if n1 <= n0:
+                return
+            dec = self._decs[self._seq & 1]
+            self._seq += 1
+            self._aheads.append([n0, n1, min(first + self._window, len(self._sizes)), read_err, dec.decode_batch_start(blob, starts), dec])
+
     def _decode_window(self, first):
-        w = self._settle()
-        if w is None or not (w[0] <= first < w[1] or (w[5] is not None and w[5][0] == first)):
-            w = self._decode(first)  # the first window, a seek, or a failed read-ahead (its error comes out here)
+        w = None
+        if self._aheads and self._aheads[0][0] == first:  # the reader walked off the end of its window into the next one
+            w = self._settle()
+            if w is not None and not (w[0] <= first < w[1] or (w[5] is not None and w[5][0] == first)):
+                w = None
+        if w is None:  # the first window, a seek, or a failed read-ahead (its error comes out here)
+            self._drop()
+            self._seq = 1
+            w = self._decode(first, self._window)
         self._install(w)
-        if w[5] is None and w[0] < w[1] < len(self._sizes):  # the window behind this one, while the caller drains this one
-            n0, n1, blob, starts, read_err = self._prepare(w[1])
-            if n1 > n0:
-                self._ahead = ((n0, n1, read_err), self._dec.decode_batch_start(blob, starts))
+        self._schedule()
 
     def _next_packet(self):
         """PCM of packet self._idx (decode.go:157-187); raises what the reference returns from Read."""
@@ -205,8 +232,9 @@ class Decoder:
         return b"".join(parts)
 
     def close(self):
-        self._settle()
-        self._dec.close()
+        self._drop()
+        for d in self._decs:
+            d.close()
 
     def __enter__(self):
         return self
@@ -215,6 +243,6 @@ class Decoder:
         self.close()
 
 
-def NewDecoder(source, device=0, window=4096):
+def NewDecoder(source, device=0, window=0):
     """NewDecoder (decode.go:50-76)."""
     return Decoder(source, device=device, window=window)

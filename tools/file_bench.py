@@ -77,7 +77,7 @@ def main():
         for it in range(iters + 1):
             t0 = time.perf_counter()
             hnd = ctypes.c_void_p()
-            rc = shim.shim_open(buf, ctypes.c_size_t(len(data)), ctypes.c_size_t(1024), ctypes.byref(hnd))
+            rc = shim.shim_open(buf, ctypes.c_size_t(len(data)), ctypes.c_size_t(0), ctypes.byref(hnd))  # 0: the decoder's own window size
             assert rc == 0, shim.shim_last_error()
             got = 0
             while True:
