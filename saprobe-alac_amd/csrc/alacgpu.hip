@@ -467,7 +467,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
                 default: quad(alac_decode_24q, mode); /* 20 and 24 */
             }
         };
-        uint32_t guess = decode_mode((uint32_t)((n + ppw - 1) / ppw), n_cu, a.cap, dec->fit_force);
+        uint32_t guess = decode_mode((uint32_t)((n + ppw - 1) / ppw), n_cu, a.cap, dec->fit_force, dec->cfg.num_channels == 1);
         if (dec->order_exp) guess = dec->order_exp; /* experiments (ALACGPU_FIRST): which launch goes first */
         narrow(guess);
         for (uint32_t mode : {kModeFit4, kModeFit5, kModeGated})
@@ -1166,7 +1166,7 @@ int alacgpu_last_dispatch(alacgpu_decoder* d, alacgpu_dispatch* out) {
     const char* narrow = "";
     if (lean && out->narrow_slots) {
         const char* q = d->cfg.bit_depth == 16 ? "alac_decode_16q" : d->cfg.bit_depth == 32 ? "alac_decode_32q" : "alac_decode_24q";
-        const uint32_t mode = decode_mode(out->narrow_slots, d->n_cu, d->last_cap, d->fit_force);
+        const uint32_t mode = decode_mode(out->narrow_slots, d->n_cu, d->last_cap, d->fit_force, d->cfg.num_channels == 1);
         narrow = mode == kModeGated ? "alac_decode_16g" : q;
         out->gated = mode == kModeGated ? 1u : 0u;
         out->workgroups_per_cu = mode == kModeGated ? pair_quota(out->narrow_slots, d->n_cu, d->last_cap) : mode;

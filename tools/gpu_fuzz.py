@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """gpu_fuzz.py — one-off randomized parity sweep on the GPU: random frame lengths (now and then 8 192 .. 70 000 frames),
-depths, channel counts, signal profiles, batch sizes, wave widths and cookie bytes KB / PB / MB (config.go:72-74), intact,
+depths, channel counts, signal profiles, batch sizes, wave widths, workgroups per CU and cookie bytes KB / PB / MB (config.go:72-74), intact,
 `loud` and corrupted packets, HIP path vs oracle through the C ABI.
 usage: python tools/gpu_fuzz.py [rounds] [seed]"""
 import importlib, os, sys
@@ -26,7 +26,7 @@ for r in range(rounds):
                            synth.PROFILE_STRESS, synth.PROFILE_MUSIC_NOSHIFT, synth.PROFILE_MUSIC_MIXED]))
     n = int(rng.choice([1, 7, 64, 65, 200, 700]))
     if rng.integers(12) == 0 and fl < 70:  # batches big enough for the gated pair kernel (16-bit) / a second round (others)
-        n = int(rng.choice([66000, 70000, 99000, 132000]))
+        n = int(rng.choice([66000, 70000, 82000, 99000, 132000, 150000]))
         ch = int(rng.choice([1, 2, 2]))
     ppw = rng.choice(["", "64", "16", "2"])
     if ppw:
@@ -38,6 +38,11 @@ for r in range(rounds):
         os.environ["ALACGPU_LANES_MIN"] = str(lm)
     else:
         os.environ.pop("ALACGPU_LANES_MIN", None)
+    fit = rng.choice(["", "", "", "4", "5"])  # four / five four-wave workgroups per CU whatever the batch size (alac_gpu.h: decode_mode; read per handle)
+    if fit:
+        os.environ["ALACGPU_FIT"] = str(fit)
+    else:
+        os.environ.pop("ALACGPU_FIT", None)
     if rng.integers(10) == 0 and fl < 300 and ch <= 2:  # full 64-packet workgroups with one or less per CU: both predictor waves at work
         n = int(rng.choice([16400, 16500, 17000]))
     kb = int(rng.choice([14, 14, 14, 14, 3, 32, 255, 0]))
@@ -69,7 +74,7 @@ for r in range(rounds):
         blob, offs, sizes = pack_packets(lp + [b.packet(i) for i in range(n - len(lp))])
     ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=8)
     if os.environ.get("ALACGPU_FUZZ_VERBOSE"):
-        print("round %d: depth %d ch %d fl %d prof %d n %d ppw %r kb %d pb %d mb %d lanes_min %r what %d" % (r, depth, ch, fl, prof, len(offs), ppw, kb, pb, mb, lm, what), flush=True)
+        print("round %d: depth %d ch %d fl %d prof %d n %d ppw %r kb %d pb %d mb %d lanes_min %r fit %r what %d" % (r, depth, ch, fl, prof, len(offs), ppw, kb, pb, mb, lm, fit, what), flush=True)
     if DRY:
         rng.integers(0, 4)
         if os.environ.get("ALACGPU_FUZZ_DUMP") == str(r):  # this round's batch and the oracle's answer, for tests/host_sim or a debugger
@@ -92,7 +97,7 @@ for r in range(rounds):
         assert_same_decode(cfg, ref, (out, fr, st), bpf, "round %d" % r)
     except AssertionError as e:
         bad += 1
-        print("MISMATCH depth %d ch %d fl %d prof %d n %d ppw %r kb %d pb %d mb %d lanes_min %r what %d: %s" % (depth, ch, fl, prof, n, ppw, kb, pb, mb, lm, what, e), flush=True)
+        print("MISMATCH depth %d ch %d fl %d prof %d n %d ppw %r kb %d pb %d mb %d lanes_min %r fit %r what %d: %s" % (depth, ch, fl, prof, n, ppw, kb, pb, mb, lm, fit, what, e), flush=True)
     if r % 50 == 49:
         print("round %d" % (r + 1), flush=True)
 print("%d rounds, %d mismatches" % (rounds, bad))
