@@ -55,8 +55,9 @@ def kernels_of(dispatch):
     parts = []
     if dispatch["narrow_slots"]:
         lanes = dispatch["lanes_per_packet"]
-        parts.append("%s (%d narrow regular wave slots of %d packets%s)" % (
-            dispatch["narrow_kernel"], dispatch["narrow_slots"], dispatch["packets_per_slot"],
+        parts.append("%s (%d narrow regular wave slots of %d packets, %d %s per CU%s)" % (
+            dispatch["narrow_kernel"], dispatch["narrow_slots"], dispatch["packets_per_slot"], dispatch["workgroups_per_cu"],
+            "wave pairs" if dispatch["gated"] else "four-wave workgroups",
             "; long predictors on %d lanes per packet" % lanes if lanes else ""))
     if dispatch["wide_slots"]:
         parts.append("%s (%d wide slots)" % (dispatch["wide_kernel"], dispatch["wide_slots"]))
@@ -288,7 +289,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5) if achieved else None,
                          "traffic": traffic, "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload and this source)") if traffic else None,
                          "kernel": kernels_of(dispatch), "kernel_from": "alacgpu_last_dispatch: the launch plan read back from the device",
-                         "dispatch": {k: dispatch[k] for k in ("slots", "irregular_slots", "wide_slots", "narrow_slots", "keys", "packets_per_slot", "gated", "lanes_per_packet")},
+                         "dispatch": {k: dispatch[k] for k in ("slots", "irregular_slots", "wide_slots", "narrow_slots", "keys", "packets_per_slot", "gated", "lanes_per_packet", "workgroups_per_cu")},
                          "valu_issue": valu_issue,
                          "kernel_ms": round(kernel_ms, 4), "kernel_ms_is": "HIP events on the handle's stream around all kernels of one decode (sort pre-pass included)",
                          "algorithmic_bytes_per_launch": alg_bytes},

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """pmc_per_sample.py <evidence dir> — wave instructions per step of 64 samples, from the pmc_summary.txt files of
-profiles/collect_round.sh (headline in the directory itself, config_b / config_c / config_d / gated_98304 below it).
+profiles/collect_round.sh (headline in the directory itself, config_b / config_c / config_d / gated_98304 / fit5_81920 below it).
 A step = one sample of one channel in each of a wave slot's 64 lanes; steps per decode = wave slots x frames x channels."""
 import os, re, sys
 
@@ -22,6 +22,7 @@ print("# wave instructions per step of 64 samples (rocprofv3 --pmc, separate pas
 for name, sub, packets, ch, fl in (("headline: 65 536 x 16-bit stereo", "", 65536, 2, 4096), ("config b: 4 096 x 16-bit stereo (16 packets per workgroup)", "config_b", 4096, 2, 4096),
                                    ("config c: 65 536 x 24-bit stereo, 1 shift byte", "config_c", 65536, 2, 4096),
                                    ("gated: 98 304 x 16-bit stereo", "gated_98304", 98304, 2, 4096),
+                                   ("five workgroups per CU: 81 920 x 24-bit stereo", "fit5_81920", 81920, 2, 4096),
                                    ("config d: 16 384 x 24-bit 8-ch", "config_d", 16384, 8, 4096)):
     d = read(os.path.join(root, sub, "pmc_summary.txt"))
     lanes = 16 if packets == 4096 and ch == 2 else 64

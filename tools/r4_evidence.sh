@@ -47,11 +47,12 @@ if has ab; then
   else say "no round-3 binary"; fi
 fi
 if has configs; then
-  say "config c / d / b and a batch between the rounds (81 920 packets: five workgroups per CU): kernel stats, PMC, traffic"
+  say "config c / d / b, the gated pairs (98 304 x 16-bit) and five workgroups per CU (81 920 x 24-bit): kernel stats, PMC, traffic"
   bash profiles/collect_round.sh "$OUT/config_c" --depth 24 > "$OUT/collect_c.log" 2>&1 || say "collect c failed"
   bash profiles/collect_round.sh "$OUT/config_d" --depth 24 --channels 8 --packets 16384 > "$OUT/collect_d.log" 2>&1 || say "collect d failed"
   bash profiles/collect_round.sh "$OUT/config_b" --packets 4096 > "$OUT/collect_b.log" 2>&1 || say "collect b failed"
-  bash profiles/collect_round.sh "$OUT/fit5_81920" --packets 81920 > "$OUT/collect_f.log" 2>&1 || say "collect f failed"
+  bash profiles/collect_round.sh "$OUT/fit5_81920" --depth 24 --packets 81920 > "$OUT/collect_f.log" 2>&1 || say "collect f failed"
+  bash profiles/collect_round.sh "$OUT/gated_98304" --packets 98304 > "$OUT/collect_g.log" 2>&1 || say "collect g failed"
   say "kernel timeline of config d"
   bash tools/kernel_timeline.sh > "$OUT/timeline_config_d.txt" 2>&1 || say "timeline failed"
   say "instruction counts per sample"
