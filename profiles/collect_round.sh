@@ -28,15 +28,19 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"].split("(")[0].split("::")[-1]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# per DECODE, not per dispatch: a kernel may be launched more than once per decode (the four-wave kernels: once per LDS footprint,
+# one of the launches exits at once; round 4), so a counter's dispatches are summed and divided by the decodes of its pass
+decodes = lambda c: max(1, len(agg["alac_classify"].get(c, [])))
 with open(os.path.join(out, "pmc_summary.txt"), "w") as w:
+    w.write("# per decode: sum over a kernel's dispatches / decodes in the pass (n = dispatches seen)\n")
     for k, d in agg.items():
         if "alac" not in k: continue
         w.write("kernel %s\n" % k)
         for c, v in sorted(d.items()):
-            w.write("  %-34s n=%d mean=%.6g\n" % (c, len(v), sum(v) / len(v)))
+            w.write("  %-34s n=%d mean=%.6g\n" % (c, len(v), sum(v) / (decodes(c) if "census" not in k else len(v))))
 sys.path.insert(0, os.getcwd())
 pkg = importlib.import_module("saprobe-alac_amd")
-mean = lambda k, c: (sum(agg[k][c]) / len(agg[k][c])) if agg[k].get(c) else 0.0
+mean = lambda k, c: (sum(agg[k][c]) / decodes(c)) if agg[k].get(c) else 0.0
 fetch = sum(mean(k, "FETCH_SIZE") for k in agg if "alac" in k) * 1024   # KB
 write = sum(mean(k, "WRITE_SIZE") for k in agg if "alac" in k) * 1024
 valu = sum(mean(k, "SQ_INSTS_VALU") for k in agg if "alac" in k and "census" not in k)  # wave-instructions per launch, all kernels of a decode

@@ -543,15 +543,18 @@ __global__ void alac_legacy(alac::DevCfg cfg, const uint8_t* __restrict__ blob, 
  * Between (5 < q <= 7.5) four per CU win (16-bit 114 688 packets 3.67 against 3.89 ms, 24-bit 98 304 4.52 against 4.64,
  * 122 880 4.58 against 4.71). */
 constexpr uint32_t kModeFit4 = 4u, kModeFit5 = 5u, kModeGated = 6u;
-/* cap: pairs per CU the width's gated twin holds (0: it has none); force (ALACGPU_FIT): 4 / 5 for every batch, no gated twin;
- * mono: single-channel streams — their workgroups have no U phase and no U tile, a round of five costs them nothing over a
- * round of four (16-bit mono 81 920 packets: 1.96 ms four per CU, 1.82 gated pairs, 1.57 five per CU) */
-constexpr __host__ __device__ __forceinline__ uint32_t decode_mode(uint32_t items, uint32_t n_cu, uint32_t cap, uint32_t force, bool mono) {
-    if (force == kModeFit4 || force == kModeFit5) return force;
+/* cap: pairs per CU the width's gated twin holds (0: it has none, or the host did not launch it for this batch); fit5: the
+ * host made the "fit 5" launch (it does both for batches of more than 4 x CUs x 64 packets: alacgpu.hip: launch; a smaller batch
+ * whose many keys push it over 4 x CUs slots all the same runs rounds of four); force (ALACGPU_FIT): 4 / 5 for every batch, no
+ * gated twin; mono: single-channel streams — their workgroups have no U phase and no U tile, a round of five costs them nothing
+ * over a round of four (16-bit mono 81 920 packets: 1.96 ms four per CU, 1.82 gated pairs, 1.57 five per CU) */
+constexpr __host__ __device__ __forceinline__ uint32_t decode_mode(uint32_t items, uint32_t n_cu, uint32_t cap, uint32_t force, bool mono,
+                                                                  bool fit5) {
+    if (force == kModeFit4 || (force == kModeFit5 && fit5)) return force;
     if (items <= 4u * n_cu) return kModeFit4;
-    if (items <= 5u * n_cu) return (cap >= 5u && !mono) ? kModeGated : kModeFit5;
+    if (items <= 5u * n_cu) return (cap >= 5u && !mono) ? kModeGated : fit5 ? kModeFit5 : kModeFit4;
     if (items <= 6u * n_cu && cap >= 6u) return kModeGated;
-    return 2u * items <= 15u * n_cu ? kModeFit4 : kModeFit5;
+    return (2u * items <= 15u * n_cu || !fit5) ? kModeFit4 : kModeFit5;
 }
 /* pairs per CU the gated twin admits (k_decode_body.inc: the gate): as few as hold the batch at once */
 constexpr __host__ __device__ __forceinline__ uint32_t pair_quota(uint32_t items, uint32_t n_cu, uint32_t cap) {
@@ -561,13 +564,19 @@ constexpr __host__ __device__ __forceinline__ uint32_t pair_quota(uint32_t items
 /* The host launches the gated twin and the "fit 5" shape only for batches whose upper bound of wave slots exceeds 4 x CUs
  * (alacgpu.hip: launch): whatever is decided above, it must never hand a batch of up to 4 x CUs slots to a launch that is
  * not made for it, or that batch stays undecoded (round 3 had such a bug once, with another guess). Checked at compile time. */
+constexpr bool mode_is_fit4_without_the_others(uint32_t n_cu) { /* no twin, no "fit 5" launch: rounds of four whatever the count */
+    for (uint32_t items = 0u; items <= 40u * n_cu; items += (items < 8u * n_cu ? 1u : n_cu / 2u + 1u))
+        if (decode_mode(items, n_cu, 0u, 0u, false, false) != kModeFit4 || decode_mode(items, n_cu, 0u, 5u, true, false) != kModeFit4) return false;
+    return true;
+}
 constexpr bool mode_is_fit4_within_four(uint32_t n_cu) {
     for (uint32_t cap = 0u; cap <= 8u; ++cap)
         for (uint32_t items = 0u; items <= 4u * n_cu; ++items)
-            if (decode_mode(items, n_cu, cap, 0u, false) != kModeFit4 || decode_mode(items, n_cu, cap, 0u, true) != kModeFit4) return false;
+            if (decode_mode(items, n_cu, cap, 0u, false, true) != kModeFit4 || decode_mode(items, n_cu, cap, 0u, true, true) != kModeFit4) return false;
     return true;
 }
-static_assert(mode_is_fit4_within_four(1u) && mode_is_fit4_within_four(7u) && mode_is_fit4_within_four(64u) &&
+static_assert(mode_is_fit4_without_the_others(1u) && mode_is_fit4_without_the_others(64u) && mode_is_fit4_without_the_others(256u) &&
+                  mode_is_fit4_within_four(1u) && mode_is_fit4_within_four(7u) && mode_is_fit4_within_four(64u) &&
                   mode_is_fit4_within_four(256u) && mode_is_fit4_within_four(304u),
               "decode_mode would leave batches of up to 4 x CUs wave slots to a launch that is not made for them");
 constexpr uint32_t kQuadLdsFit4 = 34816u; /* static + dynamic LDS of a "fit 4" launch: 4 x 34 KB <= 160 KB < 5 x 34 KB */
@@ -594,6 +603,7 @@ struct PairArgs {
     uint32_t lanes_min; /* four-wave workgroups (k_dec16q.hip): keys whose longer predictor has at least this many taps get two predictor waves */
     uint32_t fit;       /* four-wave workgroups: how many of them a CU holds with THIS launch's LDS footprint (kModeFit4 / kModeFit5) */
     uint32_t fit_force; /* experiments (ALACGPU_FIT): 4 / 5 for every batch; 0: decode_mode decides */
+    uint32_t fit5;      /* 1: the "fit 5" launch is made for this batch (decode_mode) */
 };
 #define ALAC_DECLARE_DECODE(NAME) __global__ void NAME(PairArgs);
 /* the wave pair over the regular packets, one kernel per class (sample width x channel width) */

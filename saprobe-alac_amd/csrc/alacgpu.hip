@@ -220,7 +220,7 @@ struct alacgpu_decoder {
     int ahead_rc;
     char ahead_err[512];
     size_t last_n;                                           /* the last device decode: packets, packets per wave slot, PairArgs::cap */
-    uint32_t last_ppw, last_cap;
+    uint32_t last_ppw, last_cap, last_fit5;
     uint32_t fit_force;                                      /* PairArgs::fit_force (ALACGPU_FIT) */
     uint32_t order_exp;                                      /* ALACGPU_FIRST: 4 / 5 / 6, the launch of the narrow slots that goes first (experiments) */
 };
@@ -363,7 +363,7 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
     if (rc) return rc;
     dec->last_n = n;
     dec->last_ppw = ppw;
-    dec->last_cap = 0;
+    dec->last_cap = dec->last_fit5 = 0;
     alac::DevCfg c = dec->dev_cfg;
     c.aligned16 = (out_stride % 16 == 0 && (reinterpret_cast<uintptr_t>(d_out) % 16) == 0) ? 1u : 0u;
     Plan* plan = (Plan*)dec->plan.p;
@@ -424,57 +424,58 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
          * kernel can hold (0: it has none); which of the twins works is decided on the device. */
         PairArgs a{c, d_blob, (uint64_t)blob_bytes, d_offsets, sz, (const uint32_t*)dec->perm.p, plan, d_out, (uint64_t)out_stride,
                    d_frames, d_status, (int32_t*)dec->scratch_u.p, (const uint32_t*)dec->cu_number.p,
-                   (uint32_t*)((uint8_t*)plan + plan_claims_offset()), ppw, dec->n_cu, 0u, dec->lanes_min, 4u, dec->fit_force};
+                   (uint32_t*)((uint8_t*)plan + plan_claims_offset()), ppw, dec->n_cu, 0u, dec->lanes_min, 4u, dec->fit_force, 0u};
         const uint32_t slots = (uint32_t)max_waves(dec, n, ppw);
         auto pairs = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(slots), dim3(2 * kWave), 0, dec->stream, a); };
         /* The narrow regular wave slots go to ONE of up to three launches, and which one is decided on the device from the
          * plan's count of them (alac_gpu.h: decode_mode; the host only knows an upper bound of ALL slots): the four-wave
          * kernel padded with dynamic LDS to 34 KB per workgroup ("fit 4": four per CU), the same kernel without the pad
-         * ("fit 5"), and for 16-bit streams the gated twin of wave pairs. "Fit 4" is always launched; the other two whenever
-         * the upper bound exceeds 4 x CUs slots — below that decode_mode() is "fit 4" whatever the device counts (the
-         * static_assert beside it), so nothing the device relies on is skipped. (Round 3, found by tools/gpu_fuzz.py: a
-         * host-side guess of another kind once did skip a launch the device then relied on.) The launches that are not the
-         * batch's exit at once — but an empty grid right IN FRONT of the one that works costs it up to 13 % (16-bit 98 304
-         * packets 3.15 -> 3.66 ms with the empty "fit 5" grid in front of the gated twin; behind it: nothing;
-         * profiles/r04_final/launch_order.txt), so the launch the host expects to work — decode_mode() of the batch as if
-         * every packet were a narrow regular one — goes first. A wrong guess costs speed, never correctness. */
+         * ("fit 5"), and for 16-bit streams the gated twin of wave pairs. "Fit 4" is always launched; the other two for
+         * batches of more than 4 x CUs x 64 packets (`beyond4`), and the device is TOLD whether they are (PairArgs::fit5, cap):
+         * it never picks a launch that was not made. (Round 3, found by tools/gpu_fuzz.py: a host-side guess once skipped a
+         * launch the device then relied on.) A smaller batch whose many keys push it over 4 x CUs slots all the same runs
+         * rounds of four, as in round 3; in exchange the benchmark batch and everything below it see no empty grids at all.
+         * The launches that are not the batch's exit at once — but empty grids right IN FRONT of a wave-pair kernel cost it
+         * up to 13 % (16-bit 98 304 packets 3.15 -> 3.66 ms with the empty "fit 4" and "fit 5" grids in front of the gated
+         * twin, 24-bit stereo without shift bytes 5.2 -> 8.4 ms with both in front of alac_decode_w24; one alone, or any
+         * number behind: nothing; the four-wave launches do not care; profiles/r04_final/launch_order*.txt), so the launch
+         * the host expects to work — decode_mode() of the batch as if every packet were a narrow regular one — goes first,
+         * the wide keys' pairs second, the rest behind. A wrong guess costs speed, never correctness. */
         const uint32_t n_cu = dec->n_cu;
-        const bool beyond4 = (size_t)slots > (size_t)4 * n_cu || dec->fit_force == kModeFit5;
-        auto quad = [&](auto kernel, uint32_t fit) {
-            const uint32_t stat = quad_static_lds(kernel);
-            const bool fits5 = (size_t)((stat + 1279u) / 1280u) * 1280u * 5u <= 163840u; /* 1280-byte granules of 160 KB */
-            if (fit == kModeFit5 && !(beyond4 && fits5)) return;
-            PairArgs q = a;
-            q.fit = fit;
-            hipLaunchKernelGGL(kernel, dim3(slots), dim3(4 * kWave), (fit == kModeFit4 && stat < kQuadLdsFit4) ? kQuadLdsFit4 - stat : 0u,
-                               dec->stream, q);
+        const bool beyond4 = (n + ppw - 1) / ppw > (size_t)4 * n_cu || dec->fit_force == kModeFit5;
+        const bool has_twin = dec->cfg.bit_depth == 16 && beyond4 && dec->fit_force == 0u;
+        auto quad_kernel = [&]() -> void (*)(PairArgs) {
+            return dec->cfg.bit_depth == 16 ? alac_decode_16q : dec->cfg.bit_depth == 32 ? alac_decode_32q : alac_decode_24q; /* 24: 20 and 24 */
         };
-        const bool has_twin = dec->cfg.bit_depth == 16;
-        if (has_twin) {
-            a.cap = pair_capacity(alac_decode_16g);
-            dec->last_cap = a.cap;
+        {
+            const uint32_t stat = quad_static_lds(quad_kernel());
+            a.fit5 = (beyond4 && (size_t)((stat + 1279u) / 1280u) * 1280u * 5u <= 163840u) ? 1u : 0u; /* 1280-byte granules of 160 KB */
         }
+        if (has_twin) a.cap = pair_capacity(alac_decode_16g);
+        if (a.cap <= 4u) a.cap = 0u;
+        dec->last_cap = a.cap;
+        dec->last_fit5 = a.fit5;
         auto narrow = [&](uint32_t mode) {
             if (mode == kModeGated) {
                 /* as many workgroups as the device holds at once: they share the slots out among themselves */
-                if (has_twin && beyond4 && a.cap > 4u)
-                    hipLaunchKernelGGL(alac_decode_16g, dim3(std::min<uint32_t>(a.cap * n_cu, slots)), dim3(2 * kWave), 0, dec->stream, a);
+                if (a.cap) hipLaunchKernelGGL(alac_decode_16g, dim3(std::min<uint32_t>(a.cap * n_cu, slots)), dim3(2 * kWave), 0, dec->stream, a);
                 return;
             }
-            switch (dec->cfg.bit_depth) {
-                case 16: quad(alac_decode_16q, mode); break;
-                case 32: quad(alac_decode_32q, mode); break;
-                default: quad(alac_decode_24q, mode); /* 20 and 24 */
-            }
+            if (mode == kModeFit5 && !a.fit5) return;
+            const uint32_t stat = quad_static_lds(quad_kernel());
+            PairArgs q = a;
+            q.fit = mode;
+            hipLaunchKernelGGL(quad_kernel(), dim3(slots), dim3(4 * kWave), (mode == kModeFit4 && stat < kQuadLdsFit4) ? kQuadLdsFit4 - stat : 0u,
+                               dec->stream, q);
         };
-        uint32_t guess = decode_mode((uint32_t)((n + ppw - 1) / ppw), n_cu, a.cap, dec->fit_force, dec->cfg.num_channels == 1);
+        uint32_t guess = decode_mode((uint32_t)((n + ppw - 1) / ppw), n_cu, a.cap, dec->fit_force, dec->cfg.num_channels == 1, a.fit5 != 0u);
         if (dec->order_exp) guess = dec->order_exp; /* experiments (ALACGPU_FIRST): which launch goes first */
         narrow(guess);
-        for (uint32_t mode : {kModeFit4, kModeFit5, kModeGated})
-            if (mode != guess) narrow(mode);
         /* the wide keys (chanBits > 23: 24- and 32-bit streams without their usual shift bytes): wave pairs */
         if (dec->cfg.bit_depth == 32) pairs(alac_decode_w32);
         else if (dec->cfg.bit_depth == 24) pairs(alac_decode_w24);
+        for (uint32_t mode : {kModeFit4, kModeFit5, kModeGated})
+            if (mode != guess) narrow(mode);
     }
     if (forked) scan();
     HIP_TRY(hipGetLastError());
@@ -622,7 +623,7 @@ void configure(alacgpu_decoder* d, const alacgpu_config* cfg, int bps) {
     d->ahead_rc = ALACGPU_E_OK;
     d->ahead_err[0] = 0;
     d->last_n = 0;
-    d->last_ppw = d->last_cap = 0;
+    d->last_ppw = d->last_cap = d->last_fit5 = 0;
     d->il_threads = 64;
     if (const char* e = getenv("ALACGPU_IL_THREADS")) {
         const int v = atoi(e);
@@ -1166,7 +1167,7 @@ int alacgpu_last_dispatch(alacgpu_decoder* d, alacgpu_dispatch* out) {
     const char* narrow = "";
     if (lean && out->narrow_slots) {
         const char* q = d->cfg.bit_depth == 16 ? "alac_decode_16q" : d->cfg.bit_depth == 32 ? "alac_decode_32q" : "alac_decode_24q";
-        const uint32_t mode = decode_mode(out->narrow_slots, d->n_cu, d->last_cap, d->fit_force, d->cfg.num_channels == 1);
+        const uint32_t mode = decode_mode(out->narrow_slots, d->n_cu, d->last_cap, d->fit_force, d->cfg.num_channels == 1, d->last_fit5 != 0u);
         narrow = mode == kModeGated ? "alac_decode_16g" : q;
         out->gated = mode == kModeGated ? 1u : 0u;
         out->workgroups_per_cu = mode == kModeGated ? pair_quota(out->narrow_slots, d->n_cu, d->last_cap) : mode;
@@ -1215,6 +1216,6 @@ int alacgpu_debug_prof(unsigned long long* out16) {
 }
 #endif
 
-const char* alacgpu_version(void) { return "alacgpu 0.4.0 gfx950"; }
+const char* alacgpu_version(void) { return "alacgpu 0.5.0 gfx950"; }
 
 } /* extern "C" */
