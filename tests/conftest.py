@@ -135,6 +135,33 @@ def mutate_packets(batch, rng, n_out):
     return pk
 
 
+def antiphase_packets(synth, cfg, n, seed=1, order=4, every=2):
+    """Multi-channel packets whose PAIRS are loud and in anti-phase (L = -R near full scale, a slow sine plus noise): with the
+    pair matrixed (mixRes 1) the difference channel v = L - R (matrix.go:40-41 inverted) needs all of its chanBits = depth - shift
+    + 1 = 17 bits, and the mid / side arithmetic its whole range. Every `every`-th packet is one of those, the others are quiet.
+    -> list of (packet bytes, expected PCM bytes)."""
+    rng = np.random.default_rng(seed)
+    depth, ch, fl = cfg.bit_depth, cfg.num_channels, cfg.frame_length
+    bs = {16: 0, 20: 0, 24: 1, 32: 2}[depth]
+    top = 1 << (depth - 8 * bs - 1)
+    ne = synth.num_elements(ch)
+    out = []
+    for k in range(n):
+        t = np.arange(fl)[:, None]
+        amp = (top - 40) if k % every == 0 else top // 64
+        base = (amp * np.sin(t / 9.0 + rng.uniform(0, 6.28, size=(1, ch)))).astype(np.int64) + rng.integers(-30, 31, size=(fl, ch))
+        hi = np.clip(base, -top, top - 1)
+        for c in range(0, ch - 1, 2):  # whatever the layout makes of it: neighbouring output channels in anti-phase
+            hi[:, c + 1] = np.clip(-hi[:, c] - 1, -top, top - 1)
+        if ch >= 3:
+            hi[:, 2] = np.clip(-hi[:, 1] - 1, -top, top - 1)
+        pcm = ((hi << (8 * bs)) | rng.integers(0, 1 << (8 * bs), size=(fl, ch))) if bs else hi
+        pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+        elems = [synth.default_elem(order=order, mix_res=1, mix_bits=2, bytes_shifted=bs, never_escape=1) for _ in range(ne)]
+        out.append((synth.encode_packet(cfg, elems, pcm), synth.pack_pcm(cfg, pcm)))
+    return out
+
+
 def loud_packets(synth, cfg, n, seed=1, pb_factor=7, order=0):
     """Packets whose residuals keep the Golomb mean at the top of its range: compressed elements (never the escape
     form) whose folded residuals n = 2|r| (- 1) sit in 56 000..65 535 sample after sample, with pbFactor 7 — the largest
@@ -183,6 +210,7 @@ def helpers():
     H.mutate_packets = staticmethod(mutate_packets)
     H.assert_same_decode = staticmethod(assert_same_decode)
     H.loud_packets = staticmethod(loud_packets)
+    H.antiphase_packets = staticmethod(antiphase_packets)
     return H
 
 

@@ -602,6 +602,28 @@ def test_24bit_batch_just_above_four_rounds_at_full_frame_length(pkg, synth, ora
         assert disp["workgroups_per_cu"] == 5 and disp["narrow_kernel"] == "alac_decode_24q", disp
 
 
+@pytest.mark.parametrize("depth,ch,fl", [(16, 3, 200), (16, 6, 96), (24, 8, 80), (32, 4, 64), (16, 8, 33), (20, 5, 70), (24, 8, 4096),
+                                         (16, 2, 4096), (24, 2, 512)])
+def test_pairs_whose_difference_channel_needs_17_bits_on_gpu(pkg, synth, oracle, helpers, gpu_decoder_factory, depth, ch, fl):
+    """Loud pairs in anti-phase: the difference channel of a matrixed pair uses all of its chanBits = depth - shift + 1 = 17 bits
+    (matrix.go:40-41 inverted; UnpcBlock's sign extension, predictor.go:46), a range music-like signals never reach — through the
+    split pipeline (more than two channels: scan, predictor pass over int32 rows, interleave) and through the wave workgroups of
+    the stereo kernels, between quiet packets, in batches of several waves per key. (Written for round 4's int16 rows, which
+    were measured and not kept: profiles/r04_final/experiments/rows16.txt.)"""
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    n = 40 if fl == 4096 else 300
+    pk = helpers.antiphase_packets(synth, cfg, n, seed=depth * 7 + ch, every=3)
+    packets = [p for p, _ in pk]
+    blob, offs, sizes = helpers.pack_packets(packets)
+    ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=8)
+    for i, (_, pcm) in enumerate(pk):
+        assert ref[0][i, :len(pcm)].tobytes() == pcm and ref[2][i] == 0, "oracle lost packet %d" % i
+    with gpu_decoder_factory(cfg) as dec:
+        got = _gpu_decode(dec, blob, offs, sizes)
+    helpers.assert_same_decode(cfg, ref, got, bpf, "anti-phase pairs")
+
+
 def test_gated_pairs_with_corrupt_packets_and_two_handles_at_once(pkg, synth, oracle, helpers, gpu_decoder_factory):
     """The gated kernel under the conditions the small-batch tests never reach it in: a batch of 84 000 packets of which
     every tenth is damaged (the status words of DynDecomp's error paths, golomb.go:157-163,196-199,239-245, must be the

@@ -179,6 +179,24 @@ def test_wide_channels_take_the_wave_pair(oracle, synth, lane_sim, helpers, dept
             assert len(np.unique(keys[keys < 1024])) >= (6 if ch == 2 else 3)
 
 
+@pytest.mark.parametrize("depth,ch,fl", [(16, 3, 200), (16, 6, 96), (24, 8, 80), (32, 4, 64), (16, 8, 33), (20, 5, 70)])
+def test_pairs_whose_difference_channel_needs_17_bits(oracle, synth, lane_sim, helpers, depth, ch, fl):
+    """A matrixed pair's channels have chanBits = depth - shift + 1: loud pairs in anti-phase use all 17 bits of the difference
+    channel (matrix.go:40-41 inverted) and the whole range of the mid / side arithmetic, which music-like signals never reach
+    (UnpcBlock's sign extension to chanBits, predictor.go:46,99-127; WriteStereo*, matrix.go:30). Multi-channel streams: the split
+    pipeline's int32 rows. (Written for round 4's int16 rows — profiles/r04_final/experiments/rows16.txt —, kept as a parity case.)"""
+    cfg = oracle.make_config(fl, depth, ch)
+    bpf = ch * oracle.bytes_per_sample(depth)
+    pk = helpers.antiphase_packets(synth, cfg, 24, seed=depth + ch)
+    blob, offs, sizes = helpers.pack_packets([p for p, _ in pk])
+    ref = oracle.decode_batch(cfg, blob, offs, sizes, threads=4)
+    for i, (_, pcm) in enumerate(pk):
+        assert ref[0][i, :len(pcm)].tobytes() == pcm and ref[2][i] == 0, "oracle lost packet %d" % i
+    for variant in (-1, -2, 3):
+        got = lane_sim(cfg, blob, offs, sizes, variant=variant)
+        helpers.assert_same_decode(cfg, ref, got, bpf, "anti-phase pairs, variant %d" % variant)
+
+
 def test_lane_logic_reproduces_the_hand_derived_packets(oracle, lane_sim):
     """K1..K23 (tests/golden/kat*.json, derived on paper from the reference source) through the kernel's decode logic
     as built for the host: every routing the GPU library can take for them."""
