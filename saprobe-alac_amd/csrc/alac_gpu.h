@@ -176,6 +176,14 @@ typedef uint32_t alac_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
         (d) = v_.w;                                                                     \
     } while (0)
 typedef int32_t alac_i32x4 __attribute__((ext_vector_type(4)));
+#define ALAC_LOAD4_I32(q, a, b, c, d)                                                  \
+    do {                                                                               \
+        const alac_i32x4 v_ = *reinterpret_cast<const alac_i32x4*>(q); /* 16-byte aligned */ \
+        (a) = v_.x;                                                                    \
+        (b) = v_.y;                                                                    \
+        (c) = v_.z;                                                                    \
+        (d) = v_.w;                                                                    \
+    } while (0)
 #define ALAC_STORE4(q, a, b, c, d) (*reinterpret_cast<alac_i32x4*>(q) = alac_i32x4{(a), (b), (c), (d)})
 #ifdef ALAC_DUO_PROF
 /* profiling build: cycles (s_memtime) between the stamps of alac_duo.h, summed per role over all waves into
@@ -614,6 +622,10 @@ __global__ void alac_chan_predict(alac::DevCfg cfg, const uint8_t* __restrict__ 
                                   const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
                                   const alac::ChanDesc* __restrict__ cd, int32_t* __restrict__ rows, uint64_t row_stride, uint32_t ppw);
 __global__ void alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
+                                const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
+                                const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd, const int32_t* __restrict__ rows,
+                                uint64_t row_stride, uint8_t* __restrict__ out, uint64_t out_stride, uint32_t blocks_per_pkt);
+__global__ void alac_interleave4(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
                                 const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
                                 const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd, const int32_t* __restrict__ rows,
                                 uint64_t row_stride, uint8_t* __restrict__ out, uint64_t out_stride, uint32_t blocks_per_pkt);

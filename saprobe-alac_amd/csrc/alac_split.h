@@ -166,6 +166,74 @@ ALAC_DEV void interleave_load(const DevCfg& cfg, const uint8_t* pkt, uint32_t si
     }
 }
 
+#ifndef ALAC_LOAD4_I32 /* four int32 from a 16-byte aligned address: one global_load_dwordx4 on the GPU (alac_gpu.h) */
+#define ALAC_LOAD4_I32(q, a, b, c, d) \
+    do {                              \
+        (a) = (q)[0];                 \
+        (b) = (q)[1];                 \
+        (c) = (q)[2];                 \
+        (d) = (q)[3];                 \
+    } while (0)
+#endif
+/* The same for FOUR consecutive frames i0 .. i0 + 3 (i0 a multiple of four) — round 4: alac_interleave is bound by the number of
+ * its memory requests, not by their bytes (int16 rows halved the bytes and made it slower: experiments/rows16.txt), so a lane
+ * asks for four frames' samples of a row in ONE 16-byte load (rows are 16-byte aligned, their stride a multiple of four) and
+ * for the shift values of as many frames as a window holds: Bits::window has at least 57 stream bits, a frame's shift values
+ * are nch * sb bits side by side. Rows are readable up to their stride; frames beyond a channel's count are not used
+ * (interleave_build looks at ns). */
+template <int NC, int BPS>
+ALAC_DEV void interleave_load4(const DevCfg& cfg, const uint8_t* pkt, uint32_t size, uint32_t avail, const PktDesc& pd,
+                               const ChanDesc* cd, const int32_t* rows, size_t row_stride, uint32_t i0, IlLoaded<NC> (&L)[4]) {
+    const Bits bits{pkt, size, avail};
+#pragma unroll
+    for (int slot = 0; slot < NC; ++slot) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            L[j].a[slot] = L[j].b[slot] = 0;
+            L[j].w[slot] = 0;
+        }
+        if ((uint32_t)slot >= pd.nslots) continue;
+        const ChanDesc d = cd[slot];
+        if (!(d.info & CD_VALID) || (d.info & CD_SECOND) || i0 >= d.ns) continue;
+        const bool cpe = (d.info & CD_CPE) != 0, escape = (d.info & CD_ESCAPE) != 0;
+        const uint32_t nch_e = cpe ? 2u : 1u;
+        const uint32_t chan_bits = (d.info >> CD_CHANBITS_SHIFT) & 63u;
+        const uint32_t sb = (d.info >> CD_SB_SHIFT) & 31u;
+        if (escape) { /* decodeSCEEscape / decodeCPEEscape, decoder.go:326-345 / 507-535 */
+            const uint32_t cs = 32u - chan_bits;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t i = i0 + (uint32_t)j;
+                if (i >= d.ns) continue;
+                L[j].a[slot] = sext_cs((int32_t)bits.get(d.hdr_pos + (i * nch_e) * chan_bits, chan_bits), cs);
+                if (cpe) L[j].b[slot] = sext_cs((int32_t)bits.get(d.hdr_pos + (i * nch_e + 1u) * chan_bits, chan_bits), cs);
+            }
+        } else {
+            ALAC_LOAD4_I32(rows + (size_t)slot * row_stride + i0, L[0].a[slot], L[1].a[slot], L[2].a[slot], L[3].a[slot]);
+            if (cpe && slot + 1 < NC)
+                ALAC_LOAD4_I32(rows + (size_t)(slot + 1) * row_stride + i0, L[0].b[slot], L[1].b[slot], L[2].b[slot], L[3].b[slot]);
+        }
+        if (sb) { /* matrix.go:129-132, 266-268: both shift values of a frame lie side by side (decoder.go:492-502) */
+            const uint32_t step = nch_e * sb;
+            const uint32_t sp = d.shift_pos + i0 * step;
+            if (step <= 14u) { /* four frames in one window */
+                const uint64_t w = bits.window(sp);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) L[j].w[slot] = w << ((uint32_t)j * step);
+            } else if (step <= 28u) { /* two and two */
+                const uint64_t w0 = bits.window(sp), w1 = bits.window(sp + 2u * step);
+                L[0].w[slot] = w0;
+                L[1].w[slot] = w0 << step;
+                L[2].w[slot] = w1;
+                L[3].w[slot] = w1 << step;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) L[j].w[slot] = bits.window(sp + (uint32_t)j * step);
+            }
+        }
+    }
+}
+
 template <int NC, int BPS>
 ALAC_DEV void interleave_build(const DevCfg& cfg, const PktDesc& pd, const ChanDesc* cd, uint32_t i, const IlLoaded<NC>& L,
                                uint32_t (&f)[NC * BPS / 4]) {

@@ -211,6 +211,7 @@ struct alacgpu_decoder {
     Slot slots[kSlots];                                      /* host-entry staging */
     CopyPool* pool;
     uint32_t il_threads;                                     /* alac_interleave block size (64, 128 or 256) */
+    uint32_t il_four;                                        /* alac_interleave: four frames per lane (ALACGPU_IL4) */
     uint32_t n_cu;                                           /* compute units of the device */
     DevBuf cu_number;                                        /* PairArgs::cu_number */
     size_t chunk_bytes;                                      /* host entry: target bytes (in + out) per chunk */
@@ -508,7 +509,11 @@ int launch(alacgpu_decoder* dec, const uint8_t* d_blob, uint64_t blob_bytes, con
         /* (beside the regular packets' kernels: a few blocks per CU — it walks the scanned packets, a handful there) */
         const uint32_t ib = (uint32_t)std::min<uint64_t>((uint64_t)n * ((bpp + 7u) / 8u),
                                                          forked ? (uint64_t)4 * dec->n_cu : (uint64_t)8192u * (256u / il_threads));
-        hipLaunchKernelGGL(alac_interleave, dim3(ib), dim3(il_threads), 32u * il_threads, irr, c, d_blob, blob_bytes, d_offsets, sz,
+        /* four frames per lane (k_split.hip: alac_interleave4) where the rows exist (more than two channels) and a frame is a whole
+         * number of dwords (the layouts with a register-packed form: the others build their frames byte by byte and only lose
+         * occupancy to the bigger kernel: 16-bit 3-channel 3.25 -> 3.53 ms); ALACGPU_IL4=0: one frame per lane everywhere */
+        const uint32_t il_four = (dec->cfg.num_channels > 2 && (dec->cfg.num_channels * c.bps) % 4u == 0u && dec->il_four) ? 1u : 0u;
+        hipLaunchKernelGGL(il_four ? alac_interleave4 : alac_interleave, dim3(ib), dim3(il_threads), (il_four ? 128u : 32u) * il_threads, irr, c, d_blob, blob_bytes, d_offsets, sz,
                            (const uint32_t*)dec->perm.p, (const Plan*)plan, (const alac::ChanDesc*)dec->cd.p,
                            (const alac::PktDesc*)dec->pd.p, (const int32_t*)dec->rows.p, rs, d_out, (uint64_t)out_stride, bpp);
         hipLaunchKernelGGL(alac_legacy, dim3(scan_grid), dim3(kWave), 0, irr, c, d_blob, blob_bytes,
@@ -629,6 +634,8 @@ void configure(alacgpu_decoder* d, const alacgpu_config* cfg, int bps) {
         const int v = atoi(e);
         if (v == 64 || v == 128 || v == 256) d->il_threads = (uint32_t)v;
     }
+    d->il_four = 1;
+    if (const char* e = getenv("ALACGPU_IL4")) d->il_four = (uint32_t)atoi(e);
     d->lanes_min = 4;
     d->fit_force = 0;
     if (const char* e = getenv("ALACGPU_FIT")) d->fit_force = (uint32_t)atoi(e); /* experiments: 4 / 5 workgroups per CU for every batch */
@@ -1179,7 +1186,9 @@ int alacgpu_last_dispatch(alacgpu_decoder* d, alacgpu_dispatch* out) {
              (lean && out->wide_slots) ? (d->cfg.bit_depth == 32 ? "alac_decode_w32" : "alac_decode_w24") : "");
     snprintf(out->irregular_kernels, sizeof(out->irregular_kernels), "%s",
              !out->irregular_slots ? "" : !alac::lean_config(d->dev_cfg) ? "alac_scan (whole-packet decoder)"
-             : d->cfg.num_channels > 2 ? "alac_scan + alac_chan_predict + alac_interleave (+ alac_legacy)"
+             : d->cfg.num_channels > 2 ? ((d->cfg.num_channels * d->dev_cfg.bps) % 4u == 0u && d->il_four
+                                              ? "alac_scan + alac_chan_predict + alac_interleave4 (+ alac_legacy)"
+                                              : "alac_scan + alac_chan_predict + alac_interleave (+ alac_legacy)")
                                        : "alac_scan + alac_interleave (+ alac_legacy)");
     return ALACGPU_E_OK;
 }

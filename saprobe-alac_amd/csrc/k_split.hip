@@ -95,16 +95,53 @@ static __device__ __forceinline__ void il_chunk(const alac::DevCfg& cfg, const u
     }
 }
 
+/* The same with FOUR frames per lane (alac_split.h: interleave_load4; round 4): sub-slices of 4 x blockDim.x frames, a lane's four
+ * frames side by side in the slice buffer (4 x blockDim.x x NC x BPS bytes of LDS). The kernel is bound by the number of its
+ * memory requests: a row's samples come as 16-byte loads (1 KB per wave instead of 256 bytes), the shift values of up to four
+ * frames in one window. BASELINE config d: alac_interleave 1.30 -> 1.23 ms (6.63 -> 6.49 ms in all), at 65 536 packets
+ * 17.8 -> 17.1; 165 registers (three waves per SIMD) against 72: it is what the wider requests buy, not more. */
+template <int NC, int BPS>
+static __device__ __forceinline__ void il_chunk4(const alac::DevCfg& cfg, const uint8_t* pk, uint32_t psz, uint32_t pav,
+                                                 const alac::PktDesc& q, const alac::ChanDesc* pcd, const int32_t* prow,
+                                                 size_t row_stride, uint8_t* dst_pkt, uint32_t f_begin, uint32_t f_end, uint8_t* slice) {
+    constexpr uint32_t DW = NC * BPS / 4;
+    const uint32_t span = 4u * blockDim.x;
+    alac::IlLoaded<NC> L[4];
+    uint32_t f0 = f_begin;
+    if (f0 + 4u * threadIdx.x < q.frames) alac::interleave_load4<NC, BPS>(cfg, pk, psz, pav, q, pcd, prow, row_stride, f0 + 4u * threadIdx.x, L);
+    for (; f0 < f_end && f0 < q.frames; f0 += span) {
+        const uint32_t nf = min(q.frames - f0, span);
+        const uint32_t mine = f0 + 4u * threadIdx.x;
+        if (mine < q.frames) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                if (mine + j >= q.frames) break;
+                uint32_t fr[DW];
+                alac::interleave_build<NC, BPS>(cfg, q, pcd, mine + j, L[j], fr);
+                uint32_t* dw = reinterpret_cast<uint32_t*>(slice) + (4u * threadIdx.x + j) * DW;
+#pragma unroll
+                for (uint32_t k = 0; k < DW; ++k) dw[k] = fr[k];
+            }
+        }
+        il_sync();
+        const uint32_t fn = f0 + span;
+        if (fn < f_end && fn + 4u * threadIdx.x < q.frames)
+            alac::interleave_load4<NC, BPS>(cfg, pk, psz, pav, q, pcd, prow, row_stride, fn + 4u * threadIdx.x, L);
+        il_store(dst_pkt + (size_t)f0 * (NC * BPS), slice, nf * (NC * BPS), cfg.aligned16 != 0); /* f0 is a multiple of 256: 16-byte aligned */
+        il_sync();
+    }
+}
+
 /* one thread per (packet, frame) of the split packets: PCM in frame order. Blocks stride over the scanned
  * packets (the tail of the permutation that belongs to kKeyScan) x chunks of eight blockDim.x-frame slices. A slice is
  * assembled in LDS (a frame is 1..32 bytes at a byte offset of its own) and copied out as 16-byte pieces, whole lines
  * at a time. */
-__global__ void __launch_bounds__(256)
-alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
+template <bool FOUR>
+static __device__ __forceinline__ void interleave_body(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blob_bytes, const uint64_t* __restrict__ offsets,
                 const uint32_t* __restrict__ sizes, const uint32_t* __restrict__ perm, const Plan* __restrict__ plan,
                 const alac::ChanDesc* __restrict__ cd, const alac::PktDesc* __restrict__ pd, const int32_t* __restrict__ rows,
                 uint64_t row_stride, uint8_t* __restrict__ out, uint64_t out_stride, uint32_t blocks_per_pkt) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_slice[]; /* blockDim.x frames of <= 32 bytes (launch: 32 * blockDim.x) */
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_slice[]; /* blockDim.x frames of <= 32 bytes (launch: 32 * blockDim.x), four times that with `four` */
     const uint32_t n_scan = plan->count[kKeyScan];
     const uint32_t first = plan->pkt_start[kKeyScan];
     const uint32_t fb = cfg.num_channels * cfg.bps;
@@ -126,7 +163,10 @@ alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blo
         const uint32_t s_end = min(s0 + kSlices, blocks_per_pkt);
 #define ALAC_IL_CASE(NC_, BPS_)                                                                              \
     case (NC_) * 8 + (BPS_):                                                                                 \
-        il_chunk<NC_, BPS_>(cfg, pk, psz, pav, q, pcd, prow, (size_t)row_stride, dst_pkt, s0, s_end, s_slice); \
+        if constexpr (FOUR)                                                                                  \
+            il_chunk4<NC_, BPS_>(cfg, pk, psz, pav, q, pcd, prow, (size_t)row_stride, dst_pkt, s0 * blockDim.x, s_end * blockDim.x, s_slice); \
+        else                                                                                                 \
+            il_chunk<NC_, BPS_>(cfg, pk, psz, pav, q, pcd, prow, (size_t)row_stride, dst_pkt, s0, s_end, s_slice); \
         break;
         switch (cfg.num_channels * 8u + cfg.bps) {
             ALAC_IL_CASE(4, 2) ALAC_IL_CASE(6, 2) ALAC_IL_CASE(8, 2) ALAC_IL_CASE(4, 3) ALAC_IL_CASE(8, 3)
@@ -146,5 +186,21 @@ alac_interleave(alac::DevCfg cfg, const uint8_t* __restrict__ blob, uint64_t blo
 #undef ALAC_IL_CASE
     }
 }
+
+
+#define ALAC_IL_ARGS                                                                                                                   \
+    alac::DevCfg cfg, const uint8_t *__restrict__ blob, uint64_t blob_bytes, const uint64_t *__restrict__ offsets,                    \
+        const uint32_t *__restrict__ sizes, const uint32_t *__restrict__ perm, const Plan *__restrict__ plan,                         \
+        const alac::ChanDesc *__restrict__ cd, const alac::PktDesc *__restrict__ pd, const int32_t *__restrict__ rows, uint64_t row_stride, \
+        uint8_t *__restrict__ out, uint64_t out_stride, uint32_t blocks_per_pkt
+/* one frame per lane (streams of one or two channels: escape elements only, no rows; and ALACGPU_IL4=0) */
+__global__ void __launch_bounds__(256) alac_interleave(ALAC_IL_ARGS) {
+    interleave_body<false>(cfg, blob, blob_bytes, offsets, sizes, perm, plan, cd, pd, rows, row_stride, out, out_stride, blocks_per_pkt);
+}
+/* four frames per lane (more than two channels: the rows exist); a kernel of its own so that each form has its own registers */
+__global__ void __launch_bounds__(256) alac_interleave4(ALAC_IL_ARGS) {
+    interleave_body<true>(cfg, blob, blob_bytes, offsets, sizes, perm, plan, cd, pd, rows, row_stride, out, out_stride, blocks_per_pkt);
+}
+#undef ALAC_IL_ARGS
 
 } /* namespace alack */

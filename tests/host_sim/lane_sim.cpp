@@ -195,7 +195,31 @@ extern "C" int lane_sim_decode_batch(const alacgpu_config* cfg, const uint8_t* b
                                                                               avail, cd[sl], rows.data() + rs * sl);
                     }
                 }
-                for (uint32_t f = 0; f < pd.frames; ++f) {
+                /* frames of whole dwords with sample rows: four frames per "lane", as k_split.hip's il_chunk4 loads and builds them */
+                bool done4 = false;
+                if (keep_res) {
+#define LANE_IL4_CASE(NC_, BPS_)                                                                                         \
+    case (NC_) * 8 + (BPS_): {                                                                                           \
+        for (uint32_t f0 = 0; f0 < pd.frames; f0 += 4) {                                                                 \
+            alac::IlLoaded<NC_> L4[4];                                                                                   \
+            alac::interleave_load4<NC_, BPS_>(dc, p, sizes[i], avail, pd, cd, rows.data(), rs, f0, L4);                  \
+            for (uint32_t j = 0; j < 4 && f0 + j < pd.frames; ++j) {                                                     \
+                uint32_t fr[(NC_) * (BPS_) / 4];                                                                         \
+                alac::interleave_build<NC_, BPS_>(dc, pd, cd, f0 + j, L4[j], fr);                                        \
+                memcpy(o + (size_t)(f0 + j) * dc.num_channels * dc.bps, fr, sizeof(fr));                                 \
+            }                                                                                                            \
+        }                                                                                                                \
+        done4 = true;                                                                                                    \
+        break;                                                                                                           \
+    }
+                    switch (dc.num_channels * 8u + dc.bps) {
+                        LANE_IL4_CASE(4, 2) LANE_IL4_CASE(6, 2) LANE_IL4_CASE(8, 2) LANE_IL4_CASE(4, 3) LANE_IL4_CASE(8, 3)
+                        LANE_IL4_CASE(3, 4) LANE_IL4_CASE(4, 4) LANE_IL4_CASE(5, 4) LANE_IL4_CASE(6, 4) LANE_IL4_CASE(7, 4) LANE_IL4_CASE(8, 4)
+                        default: break;
+                    }
+#undef LANE_IL4_CASE
+                }
+                for (uint32_t f = 0; f < pd.frames && !done4; ++f) {
                     uint8_t* dst = o + (size_t)f * dc.num_channels * dc.bps;
                     /* the register-packed form for frames of whole dwords, as alac_interleave picks it */
 #define LANE_IL_CASE(NC_, BPS_)                                                                               \
