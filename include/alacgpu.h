@@ -167,7 +167,8 @@ int alacgpu_decode_batch(alacgpu_decoder* dec, const uint8_t* blob, size_t blob_
  * returns what alacgpu_decode_batch would have (its error text becomes the waiting thread's alacgpu_last_error). One
  * decode in flight per handle; nothing else may be called on the handle in between (alacgpu_destroy waits by itself), and
  * all buffers stay the caller's to keep alive and untouched until _wait returns. What a read-ahead file decoder needs:
- * window k + 1 is decoded while the caller drains window k (host/stream_decoder.hpp, stream.py, go/alacgpu_decoder.go). */
+ * window k + 1 is decoded while the caller drains window k (host/stream_decoder.hpp, stream.py, go/alacgpu_decoder.go): the
+ * batch form of the reference's Read loop, which decodes the packet it is about to hand out (decode.go:157-186). */
 int alacgpu_decode_batch_start(alacgpu_decoder* dec, const uint8_t* blob, size_t blob_bytes, const uint64_t* offsets,
                                size_t n_packets, uint8_t* out, size_t out_stride, uint32_t* frames_out, int32_t* status);
 int alacgpu_decode_batch_wait(alacgpu_decoder* dec);
