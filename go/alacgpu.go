@@ -93,6 +93,25 @@ func (d *GPUPacketDecoder) Close() {
 // Format returns the PCM output format (decoder.go:112).
 func (d *GPUPacketDecoder) Format() PCMFormat { return d.format }
 
+// Reserve sizes the handle's device workspace for batches of up to n packets. The batch entries grow it on demand, but a buffer
+// that has to grow is freed first, and hipFree waits for the whole device: a caller that decodes batch after batch (a file
+// decoder's windows) reserves for its largest one before the first decode (include/alacgpu.h: alacgpu_reserve).
+func (d *GPUPacketDecoder) Reserve(n int) error {
+	if n <= 0 {
+		return nil
+	}
+
+	if rc := C.alacgpu_reserve(d.h, C.size_t(n)); rc != C.ALACGPU_E_OK {
+		return fmt.Errorf("alacgpu: %s", C.GoString(C.alacgpu_last_error()))
+	}
+
+	return nil
+}
+
+// TrimGPUPool frees what closed decoders left in the library's per-process pools (handles with their streams and up to 2 GB
+// of device memory each, pinned host blocks): include/alacgpu.h: alacgpu_trim.
+func TrimGPUPool() { C.alacgpu_trim() }
+
 // statusErr rebuilds the reference's error chain (decoder.go:144-189,303,468,482) from a status word.
 func statusErr(st int32) error {
 	var sentinel error

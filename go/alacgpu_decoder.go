@@ -69,6 +69,14 @@ func NewGPUDecoder(rs io.ReadSeeker, device, window int) (*GPUDecoder, error) {
 		window = DefaultGPUWindow
 	}
 
+	// every window has the same size and the workspace for it exists before the first one is decoded: a buffer that grows in
+	// the middle of a stream is freed first, which stalls the device (host/stream_decoder.hpp learned that in round 4)
+	if err := dec.Reserve(min(window, len(samples))); err != nil {
+		dec.Close()
+
+		return nil, err
+	}
+
 	bps := alacint.BytesPerSample(config.BitDepth)
 
 	return &GPUDecoder{
